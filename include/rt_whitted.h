@@ -1,0 +1,271 @@
+/*
+ * rt_whitted.h — C ABI of the MI355X-native Whitted render path.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and
+ * sizes, no C++/torch types. Every entry point names the reference interface
+ * it replaces (paths relative to the reference tree). The reference-side
+ * binding a maintainer would add is shown in INTEGRATION.md; a C++ shim with
+ * the reference's own names (renderRayTracing / getFinalColor / BvhInterface)
+ * lives in computer-graphics-engine_amd/host/reference_api.hpp.
+ *
+ * Conventions
+ *   - every function returns an int status (RT_OK == 0); no exception crosses
+ *     the boundary; rt_last_error() gives a thread-local message.
+ *   - "prim id" = index of the primitive in the PRE-permutation list of
+ *     src/bounding_volume_hierarchy.cpp:158-172: triangles mesh-major in
+ *     scene.meshes order, then mesh.triangles order, followed by spheres.
+ *     Miss = -1.
+ *   - framebuffers are W*H*3 fp32, row-flipped like Screen::setPixel
+ *     (src/screen.cpp:41-47): pixel (x,y) lives at ((H-1-y)*W + x)*3.
+ *   - pointers named *_dev are device (HBM) pointers, everything else is host
+ *     memory. Scene data is copied at rt_scene_create (the reference borrows a
+ *     Scene*, src/bounding_volume_hierarchy.h:86).
+ */
+#ifndef RT_WHITTED_H
+#define RT_WHITTED_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,      /* bad argument / descriptor */
+    RT_ERR_UNSUPPORTED = 2,  /* a Features flag outside the hot-path scope */
+    RT_ERR_DEVICE = 3,       /* HIP runtime error (message in rt_last_error) */
+    RT_ERR_NOMEM = 4
+};
+
+/* ---- Features: byte-for-byte the layout of `Features` + `ExtraFeatures`
+ * (src/common.h:54-77, 17 one-byte bools) so a `const Features&` can be
+ * passed as `(const rt_features*)&features`. ------------------------------ */
+typedef struct rt_features {
+    uint8_t enableShading;
+    uint8_t enableRecursive;
+    uint8_t enableHardShadow;
+    uint8_t enableSoftShadow;
+    uint8_t enableNormalInterp;
+    uint8_t enableTextureMapping;
+    uint8_t enableAccelStructure;
+    /* ExtraFeatures (src/common.h:54-65) */
+    uint8_t enableEnvironmentMapping;
+    uint8_t enableBvhSahBinning;
+    uint8_t enableMotionBlur;
+    uint8_t enableBloomEffect;
+    uint8_t enableBilinearTextureFiltering;
+    uint8_t enableMipmapTextureFiltering;
+    uint8_t enableMultipleRaysPerPixel;
+    uint8_t enableGlossyReflection;
+    uint8_t enableTransparency;
+    uint8_t enableDepthOfField;
+} rt_features;
+
+/* ---- Ray: layout of framework/include/framework/ray.h:9-13 (28 bytes) ---- */
+typedef struct rt_ray {
+    float origin[3];
+    float direction[3];
+    float t;
+} rt_ray;
+
+/* ---- Material without the shared_ptr<Image> (framework mesh.h:22-34) ----- */
+typedef struct rt_material {
+    float kd[3];
+    float ks[3];
+    float shininess;
+    float transparency;
+    int32_t texture; /* index into rt_scene_desc.textures, -1 = none (kdTexture) */
+} rt_material;
+
+/* ---- Mesh (framework mesh.h:36-43): SoA view of Vertex{position,normal,
+ * texCoord} + uvec3 triangles + Material ---------------------------------- */
+typedef struct rt_mesh_desc {
+    const float* positions;    /* n_vertices * 3 */
+    const float* normals;      /* n_vertices * 3 */
+    const float* texcoords;    /* n_vertices * 2 */
+    const uint32_t* triangles; /* n_triangles * 3 vertex indices */
+    uint32_t n_vertices;
+    uint32_t n_triangles;
+    rt_material material;
+} rt_mesh_desc;
+
+/* ---- Sphere (src/common.h:31-35) ---------------------------------------- */
+typedef struct rt_sphere_desc {
+    float center[3];
+    float radius;
+    rt_material material; /* texture ignored (spheres are never textured) */
+} rt_sphere_desc;
+
+/* ---- Lights: tagged union of PointLight / SegmentLight / ParallelogramLight
+ * (src/common.h:37-52). v[] holds the struct's vec3 members in declaration
+ * order: point {position,color}; segment {endpoint0,endpoint1,color0,color1};
+ * parallelogram {v0,edge01,edge02,color0,color1,color2,color3}. ------------ */
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_SEGMENT = 1, RT_LIGHT_PARALLELOGRAM = 2 };
+typedef struct rt_light_desc {
+    int32_t kind;
+    float v[7][3];
+} rt_light_desc;
+
+/* ---- Image (framework image.h:11-18): fp32 RGB, row-major ---------------- */
+typedef struct rt_texture_desc {
+    const float* pixels; /* width*height*3 */
+    int32_t width;
+    int32_t height;
+} rt_texture_desc;
+
+/* ---- Scene (src/scene.h:28-33) ------------------------------------------ */
+typedef struct rt_scene_desc {
+    const rt_mesh_desc* meshes;
+    uint32_t n_meshes;
+    const rt_sphere_desc* spheres;
+    uint32_t n_spheres;
+    const rt_light_desc* lights;
+    uint32_t n_lights;
+    const rt_texture_desc* textures;
+    uint32_t n_textures;
+} rt_scene_desc;
+
+/* ---- Camera: what Trackball::generateRay / position() need
+ * (framework/src/trackball.cpp:101-110, 71-74, 26-27) ---------------------- */
+typedef struct rt_camera {
+    float origin[3]; /* Trackball::position() */
+    float quat[4];   /* glm::quat(eulerAngles) as (w,x,y,z) */
+    float half_w;    /* m_halfScreenSpaceWidth  = aspect * tan(fovy/2) */
+    float half_h;    /* m_halfScreenSpaceHeight = tan(fovy/2) */
+} rt_camera;
+
+/* ---- per-ray hit record, ≙ the observable result of
+ * BvhInterface::intersect (src/bvh_interface.h:45): return value, ray.t,
+ * HitInfo.normal, HitInfo.material (kd after texture lookup) ---------------- */
+typedef struct rt_hit {
+    int32_t hit;   /* 0 / 1 */
+    int32_t prim;  /* prim id (see above), -1 on miss */
+    float t;       /* ray.t after the call */
+    float normal[3];
+    rt_material material; /* .texture = source mesh's texture index */
+} rt_hit;
+
+/* ---- explicit render parameters that are globals / literals in the
+ * reference: recursion depth (literal 5 at src/render.cpp:318),
+ * parallelogramLightDirectionSamples / segmentLightSamples
+ * (src/light.cpp:12-13) and the area-light RNG seed (reference: rand()) ---- */
+typedef struct rt_render_params {
+    int32_t depth;            /* rayDepth passed to getFinalColor */
+    int32_t parallelogram_n;  /* samples per side (reference default 5) */
+    int32_t segment_n;        /* samples (reference default 25) */
+    uint32_t seed;            /* counter-based RNG seed */
+} rt_render_params;
+
+/* ---- ray / test counters of one call (what SURVEY.md §8(d) prices) ------- */
+typedef struct rt_counters {
+    uint64_t rays;        /* BvhInterface::intersect call equivalents traced */
+    uint64_t rays_primary;
+    uint64_t rays_shadow;
+    uint64_t rays_reflect;   /* distinct reflection rays traversed */
+    uint64_t rays_ref_equiv; /* what the reference would count (reflections x2^k) */
+    uint64_t box_tests;      /* ray-AABB slab tests (lane-level) */
+    uint64_t tri_tests;      /* ray-triangle tests (lane-level) */
+    uint64_t sphere_tests;
+    uint64_t node_fetches;   /* wave-level internal-node fetches (64 B each) */
+    uint64_t tri_fetches;    /* wave-level triangle fetches */
+} rt_counters;
+
+typedef struct rt_scene rt_scene; /* opaque */
+typedef struct rt_bvh rt_bvh;     /* opaque */
+
+/* thread-local description of the last failure on the calling thread */
+const char* rt_last_error(void);
+
+/* library / device info: returns RT_ERR_DEVICE when no gfx950 device or the
+ * HIP runtime is unusable. The product path never falls back to the CPU. */
+int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len);
+
+/* Select the HIP device used by subsequent creates on this thread. */
+int rt_set_device(int device);
+
+/* -- Scene ≙ `Scene` value + loadScene* results (src/scene.h:28-33). Copies
+ *    everything (host flatten + device upload). ----------------------------- */
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
+int rt_scene_destroy(rt_scene* scene);
+/* The GUI moves lights between frames (src/main.cpp:296-368). */
+int rt_scene_update_lights(rt_scene* scene, const rt_light_desc* lights, uint32_t n_lights);
+
+/* -- BVH ≙ BvhInterface::BvhInterface(Scene*, const Features&)
+ *    (src/bvh_interface.cpp:6-9 → src/bounding_volume_hierarchy.cpp:149-194).
+ *    Host C++ build (same split sequence), SoA flatten, device upload. ------ */
+int rt_bvh_build(rt_scene* scene, const rt_features* features, rt_bvh** out);
+int rt_bvh_destroy(rt_bvh* bvh);
+/* ≙ BvhInterface::numLevels()/numLeaves() (src/bvh_interface.h:20,24) */
+int rt_bvh_num_levels(const rt_bvh* bvh);
+int rt_bvh_num_leaves(const rt_bvh* bvh);
+int rt_bvh_num_nodes(const rt_bvh* bvh);
+int rt_bvh_num_prims(const rt_bvh* bvh);
+/* Debug/parity export of the reference-shaped tree: post-order nodes
+ * (root = last). node_aabb: n*6 floats (lower,upper); node_meta: n*6 int32
+ * {leaf, depth, beg, end, left, right} (left/right = -1 for leaves);
+ * prim_order: n_prims int32 = prim id stored at each permuted position.
+ * Any pointer may be NULL. */
+int rt_bvh_export(const rt_bvh* bvh, float* node_aabb, int32_t* node_meta, int32_t* prim_order);
+
+/* -- Camera helper ≙ Trackball ctor + setCamera + position()
+ *    (framework/src/trackball.cpp:23-31,64-74). Angles in radians. ---------- */
+int rt_camera_from_trackball(float fovy, float aspect, const float look_at[3], float distance,
+                             const float rotation_euler[3], rt_camera* out);
+
+/* -- Frame ≙ renderRayTracing (src/render.cpp:273-329, plain path :316-323)
+ *    with explicit depth. Renders image rows [row_begin,row_end) of a W x H
+ *    frame (row = the reference's loop variable y, bottom-up) and writes them
+ *    at their row-flipped position of the FULL frame buffer `rgb` (host). ---- */
+int rt_render(const rt_bvh* bvh, const rt_camera* camera, const rt_features* features,
+              const rt_render_params* params, int32_t width, int32_t height,
+              int32_t row_begin, int32_t row_end, float* rgb, rt_counters* counters);
+
+/* Same, framebuffer resident in HBM; enqueued on `hip_stream` (a hipStream_t,
+ * NULL = default stream) without host synchronisation. `rows` lists the image
+ * rows this call renders (host array, n_rows entries; NULL = all rows
+ * [0,height)); row i of the list is written to packed row i of `rgb_dev` when
+ * `packed` != 0, otherwise to its row-flipped place in a full W*H frame.
+ * counters_dev (device, may be NULL) receives an rt_counters. */
+int rt_render_device(const rt_bvh* bvh, const rt_camera* camera, const rt_features* features,
+                     const rt_render_params* params, int32_t width, int32_t height,
+                     const int32_t* rows, int32_t n_rows, int32_t packed, float* rgb_dev,
+                     rt_counters* counters_dev, void* hip_stream);
+
+/* Primary-ray hit records of a frame (parity instrument: bit patterns of t and
+ * prim ids at full resolution). t_bits/prim: W*H entries, row-flipped like the
+ * framebuffer. Host pointers. */
+int rt_render_hits(const rt_bvh* bvh, const rt_camera* camera, const rt_features* features,
+                   int32_t width, int32_t height, uint32_t* t_bits, int32_t* prim);
+
+/* -- Batch of rays ≙ getFinalColor (src/render.cpp:152-155): rgb[i] =
+ *    getFinalColor(scene, bvh, rays[i], features, params->depth). pixel_ids
+ *    (may be NULL → i) key the area-light RNG. Host pointers. --------------- */
+int rt_trace_batch(const rt_bvh* bvh, const rt_ray* rays, uint32_t n_rays, const uint32_t* pixel_ids,
+                   const rt_features* features, const rt_render_params* params, float* rgb,
+                   rt_counters* counters);
+
+/* -- Batch of rays ≙ BvhInterface::intersect (src/bvh_interface.cpp:62 →
+ *    src/bounding_volume_hierarchy.cpp:299-427): rays[i].t is updated in
+ *    place, hits[i] filled. Host pointers. ---------------------------------- */
+int rt_intersect_batch(const rt_bvh* bvh, rt_ray* rays, uint32_t n_rays, const rt_features* features,
+                       rt_hit* hits, rt_counters* counters);
+
+/* -- Multi-GPU strip de-interleave: gathered packed strips
+ *    of all ranks → the reference's row-flipped frame. gathered_dev holds
+ *    n_ranks blocks of rows_per_rank_max*W*3 floats; strip s (strip_rows image
+ *    rows) belongs to rank s % n_ranks. Device pointers, enqueued on stream. - */
+int rt_deinterleave_strips(const float* gathered_dev, float* frame_dev, int32_t width, int32_t height,
+                           int32_t strip_rows, int32_t n_ranks, void* hip_stream);
+
+/* The area-light RNG (replaces rand(), src/light.cpp:21,32-33): 31-bit value
+ * for (seed, pixel id, recursion level, light index, sample index, dim). */
+uint32_t rt_rand31(uint32_t seed, uint32_t pixel, uint32_t level, uint32_t light, uint32_t sample,
+                   uint32_t dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_WHITTED_H */

@@ -1,0 +1,1111 @@
+/*
+ * whitted_oracle.cpp — CPU restatement of the reference's Whitted render path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under computer-graphics-engine_amd/ may
+ * include, link or call this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker / CPU baseline.
+ *
+ * It follows the reference function by function, scalar, array-of-structs,
+ * unpruned, with the reference's operation order (every + - * / sqrt a
+ * separately rounded binary32 op; build with -ffp-contract=off, no -march, no
+ * -ffast-math). Paths below are relative to the reference tree.
+ *
+ * Pinning status (see DESIGN.md "Oracle pinning"):
+ *   pinned by reference code run in the build container (oracle/_ref, tests/
+ *   golden): scene ingestion values, BVH build (node array + primitive
+ *   permutation), computeShading, computeReflectionRay, computeBarycentricCoord,
+ *   interpolateNormal, interpolateTexCoord, acquireTexel, point-light loop of
+ *   computeLightContribution, glm camera math.
+ *   PARITY UNPINNED by execution: the four primitive tests (the reference ships
+ *   them only as prebuilt/libIntersect_*.a, which this pipeline never loads;
+ *   src/intersect.cpp is TODO stubs) — restated from SURVEY.md Appendix A, the
+ *   decoded semantics of that archive — and, through them, BVH traversal, the
+ *   shadow test and the pixel loop (their own code is restated line by line
+ *   from the sources cited below).
+ */
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../include/rt_whitted.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+struct V2 {
+    float x, y;
+};
+
+inline V3 v3(float x, float y, float z) { return V3 { x, y, z }; }
+inline V3 v3(const float* p) { return V3 { p[0], p[1], p[2] }; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+inline V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+inline bool operator==(V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// glm/detail/func_geometric.inl:48-55 — tmp = a*b; tmp.x + tmp.y + tmp.z
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// glm/detail/func_geometric.inl:68-79
+inline V3 cross(V3 x, V3 y)
+{
+    return v3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+// glm/detail/func_geometric.inl:82-90 + func_exponential.inl:134-139
+inline V3 normalize(V3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
+// glm/detail/func_geometric.inl:8-14
+inline float length(V3 v) { return std::sqrt(dot(v, v)); }
+
+// x86 minss/maxss as emitted for std::min/std::max style selects: the second
+// operand is returned when the compare is false or unordered.
+inline float sel_min(float a, float b) { return a < b ? a : b; }
+inline float sel_max(float a, float b) { return a > b ? a : b; }
+
+struct Vertex {
+    V3 position, normal;
+    V2 texCoord;
+};
+struct Material {
+    V3 kd, ks;
+    float shininess, transparency;
+    int texture;
+};
+struct Mesh {
+    std::vector<Vertex> vertices;
+    std::vector<uint32_t> triangles; // 3 per triangle
+    Material material;
+};
+struct Sphere {
+    V3 center;
+    float radius;
+    Material material;
+};
+struct Light {
+    int kind;
+    V3 v[7];
+};
+struct Image {
+    int width, height;
+    std::vector<V3> pixels;
+};
+
+struct Ray {
+    V3 origin { 0, 0, 0 };
+    V3 direction { 0, 0, -1 };
+    float t { FLT_MAX };
+};
+struct HitInfo {
+    V3 normal { 0, 0, 0 };
+    Material material { { 0, 0, 0 }, { 0, 0, 0 }, 1.0f, 1.0f, -1 };
+};
+struct AABB {
+    V3 lower, upper;
+};
+
+// src/bounding_volume_hierarchy.h:11-23
+struct Primitive {
+    int isSphere;
+    uint32_t meshIdx, v1, v2, v3; // triangle
+    uint32_t sphereIdx;
+    V3 center;
+    int32_t id; // pre-permutation index (harness bookkeeping, not in the reference)
+};
+// src/bounding_volume_hierarchy.h:31-41
+struct Node {
+    AABB aabb;
+    int leaf;
+    uint32_t depth, beg, end, left, right;
+};
+
+const uint32_t MAX_DEPTH = 16; // src/bounding_volume_hierarchy.h:43
+const uint32_t NUM_OF_BINS = 8; // :44
+
+struct Counters {
+    uint64_t rays = 0, rays_primary = 0, rays_shadow = 0, rays_reflect = 0;
+    uint64_t box_tests = 0, tri_tests = 0, sphere_tests = 0;
+};
+
+} // namespace
+
+struct orc_scene {
+    std::vector<Mesh> meshes;
+    std::vector<Sphere> spheres;
+    std::vector<Light> lights;
+    std::vector<Image> textures;
+    std::vector<uint32_t> meshPrimBase; // first prim id of each mesh
+};
+
+struct orc_bvh {
+    orc_scene* scene;
+    std::vector<Primitive> primitives;
+    std::vector<Node> nodes;
+    uint32_t root = 0;
+    int numLevels = 0, numLeaves = 0;
+    bool sah = false;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Primitive tests — SURVEY.md Appendix A (decoded prebuilt/libIntersect_linux_x64.a;
+// declarations src/intersect.h:5-16).
+// ---------------------------------------------------------------------------
+
+// A.1 pointInTriangle
+inline bool pointInTriangle(V3 v0, V3 v1, V3 v2, V3 n, V3 p)
+{
+    if (!(dot(cross(v2 - v0, n), p - v0) >= 0.0f))
+        return false;
+    if (!(dot(cross(v0 - v1, n), p - v1) >= 0.0f))
+        return false;
+    if (!(dot(cross(v1 - v2, n), p - v2) >= 0.0f))
+        return false;
+    return true;
+}
+
+// A.2 intersectRayWithTriangle (trianglePlane + intersectRayWithPlane inlined)
+inline bool intersectRayWithTriangle(V3 v0, V3 v1, V3 v2, Ray& ray)
+{
+    V3 n = normalize(cross(v1 - v0, v2 - v0));
+    float D = dot(v0, n);
+    float t = (D - dot(ray.origin, n)) / dot(ray.direction, n);
+    if (!(t >= 0.0f))
+        return false;
+    if (!(ray.t >= t))
+        return false;
+    V3 p = ray.direction * t + ray.origin;
+    if (!pointInTriangle(v0, v1, v2, n, p))
+        return false;
+    ray.t = t;
+    return true;
+}
+
+// A.3 intersectRayWithShape(Sphere)
+inline bool intersectRayWithSphere(const Sphere& s, Ray& ray, HitInfo& hitInfo)
+{
+    V3 oc = ray.origin - s.center;
+    float h = dot(ray.direction, oc);
+    float B = h + h;
+    float C = dot(oc, oc) - s.radius * s.radius;
+    float disc = B * B - C * 4.0f;
+    if (disc < 0.0f)
+        return false;
+    float t0, t1;
+    if (disc == 0.0f) {
+        t0 = t1 = 0.5f * (-B);
+    } else {
+        float q = std::sqrt(disc);
+        t1 = (q - B) * 0.5f;
+        t0 = ((-B) - q) * 0.5f;
+    }
+    float t = FLT_MAX;
+    if (t1 >= 0.0f) {
+        if (t0 >= 0.0f)
+            t = sel_min(t0, t1);
+        else if (t1 <= FLT_MAX)
+            t = t1;
+    } else if (t0 >= 0.0f && t0 < FLT_MAX) {
+        t = t0;
+    }
+    if (t < 0.0f || t >= ray.t)
+        return false;
+    hitInfo.material = s.material;
+    hitInfo.normal = normalize((ray.direction * t + ray.origin) - s.center);
+    ray.t = t;
+    return true;
+}
+
+// A.4 intersectRayWithShape(AxisAlignedBox)
+inline bool intersectRayWithBox(const AABB& b, Ray& ray)
+{
+    const float o[3] = { ray.origin.x, ray.origin.y, ray.origin.z };
+    const float d[3] = { ray.direction.x, ray.direction.y, ray.direction.z };
+    const float bl[3] = { b.lower.x, b.lower.y, b.lower.z };
+    const float bu[3] = { b.upper.x, b.upper.y, b.upper.z };
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) {
+        if (d[a] == 0.0f) {
+            lo[a] = FLT_MIN;
+            hi[a] = FLT_MAX;
+        } else {
+            lo[a] = (bl[a] - o[a]) / d[a];
+            hi[a] = (bu[a] - o[a]) / d[a];
+        }
+    }
+    float tin = sel_max(sel_min(hi[2], lo[2]), sel_max(sel_min(hi[1], lo[1]), sel_min(hi[0], lo[0])));
+    float tout = sel_min(sel_max(hi[2], lo[2]), sel_min(sel_max(hi[1], lo[1]), sel_max(hi[0], lo[0])));
+    if (tin < 0.0f) {
+        if (!(tout > 0.0f))
+            return false;
+        tin = tout;
+        tout = FLT_MAX;
+    }
+    if (tin > tout || tin < 0.0f || tin > ray.t)
+        return false;
+    ray.t = tin;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// src/interpolate.cpp:4-28
+// ---------------------------------------------------------------------------
+inline V3 computeBarycentricCoord(V3 v0, V3 v1, V3 v2, V3 p)
+{
+    V3 a = v1 - v0, b = v2 - v0, c = p - v0;
+    float d00 = dot(a, a);
+    float d01 = dot(a, b);
+    float d11 = dot(b, b);
+    float d20 = dot(c, a);
+    float d21 = dot(c, b);
+    float denom = d00 * d11 - d01 * d01;
+    float v = (d11 * d20 - d01 * d21) / denom;
+    float w = (d00 * d21 - d01 * d20) / denom;
+    float u = 1.0f - v - w;
+    return v3(u, v, w);
+}
+inline V3 interpolateNormal(V3 n0, V3 n1, V3 n2, V3 bc)
+{
+    return normalize((n0 * bc.x + n1 * bc.y + n2 * bc.z) / 3.0f);
+}
+inline V2 interpolateTexCoord(V2 t0, V2 t1, V2 t2, V3 bc)
+{
+    return V2 { (bc.x * t0.x + bc.y * t1.x) + bc.z * t2.x, (bc.x * t0.y + bc.y * t1.y) + bc.z * t2.y };
+}
+
+// ---------------------------------------------------------------------------
+// src/texture.cpp:8-48
+// ---------------------------------------------------------------------------
+inline int f2i_x86(float f)
+{
+    // cvttss2si: out-of-range and NaN give INT_MIN ("integer indefinite")
+    if (!(f > -2147483904.0f && f < 2147483648.0f))
+        return INT32_MIN;
+    return (int)f;
+}
+inline V3 acquireTexel(const Image& image, V2 texCoord, const rt_features& f)
+{
+    if (!f.enableTextureMapping)
+        return image.pixels[0];
+    if (!f.enableBilinearTextureFiltering) {
+        // std::max(a, 0.0f) == (a < 0.0f) ? 0.0f : a
+        float fi = texCoord.x * (float)image.width;
+        float fj = (1.0f - texCoord.y) * (float)image.height;
+        int i = f2i_x86(fi < 0.0f ? 0.0f : fi);
+        int j = f2i_x86(fj < 0.0f ? 0.0f : fj);
+        i = std::min(i, image.width - 1);
+        j = std::min(j, image.height - 1);
+        // (i or j == INT_MIN indexes out of bounds in the reference: undefined.
+        //  The oracle clamps to 0 to stay memory-safe; the HIP path does the same.)
+        if (i < 0)
+            i = 0;
+        if (j < 0)
+            j = 0;
+        return image.pixels[(size_t)j * image.width + i];
+    }
+    // bilinear (src/texture.cpp:30-47)
+    float fx = texCoord.x * (float)image.width;
+    float fy = (1.0f - texCoord.y) * (float)image.height;
+    auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); };
+    float yUp = clampf(std::ceil(fy), 0.0f, (float)image.height - 1);
+    float xUp = clampf(std::ceil(fx), 0.0f, (float)image.width - 1);
+    float yDown = clampf(std::floor(fy), 0.0f, (float)image.height - 1);
+    float xDown = clampf(std::floor(fx), 0.0f, (float)image.width - 1);
+    float xSplit = std::fmod(fx, 1.0f);
+    float ySplit = std::fmod(fy, 1.0f);
+    auto at = [&](float y, float x) { return image.pixels[(size_t)(y * image.width + x)]; };
+    V3 xdyd = at(yDown, xDown), xdyu = at(yUp, xDown), xuyd = at(yDown, xUp), xuyu = at(yUp, xUp);
+    V3 x1 = (1 - xSplit) * xdyd + xSplit * xuyd;
+    V3 x2 = (1 - xSplit) * xdyu + xSplit * xuyu;
+    return (1 - ySplit) * x1 + ySplit * x2;
+}
+
+// ---------------------------------------------------------------------------
+// src/shading.cpp:7-62
+// ---------------------------------------------------------------------------
+inline V3 computeShading(V3 lightPosition, V3 lightColor, const rt_features& f, const Ray& ray, const HitInfo& hitInfo)
+{
+    if (!f.enableShading)
+        return v3(0, 0, 0);
+    V3 newNormal = normalize(hitInfo.normal);
+    V3 light = normalize(lightPosition - (ray.direction * ray.t + ray.origin));
+    float d = dot(newNormal, light);
+    if (d < 0)
+        d = 0;
+    V3 diffuse = hitInfo.material.kd * lightColor * d;
+    V3 camera = normalize(ray.direction);
+    d = 0.0f;
+    if (dot(newNormal, light) > 0 && dot(newNormal, camera) > 0) {
+        V3 reflection = (2.0f * dot(light, newNormal)) * newNormal - light;
+        d = std::pow(dot(camera, reflection), hitInfo.material.shininess); // float overload = powf
+    }
+    V3 specular = hitInfo.material.ks * lightColor * d;
+    return diffuse + specular;
+}
+
+inline Ray computeReflectionRay(const Ray& ray, const HitInfo& hitInfo)
+{
+    if (hitInfo.material.ks == v3(0, 0, 0)) {
+        Ray r;
+        r.direction.z = 0.0f;
+        r.t = 0.0f;
+        return r;
+    }
+    Ray reflectionRay;
+    V3 point = ray.t * ray.direction + ray.origin;
+    V3 n = normalize(hitInfo.normal);
+    V3 r = normalize(-ray.direction);
+    V3 reflect = normalize((2.0f * dot(n, r)) * n - r);
+    reflectionRay.origin = point + 0.00001f * n;
+    reflectionRay.direction = reflect;
+    return reflectionRay; // t = FLT_MAX (Ray{} default)
+}
+
+inline bool isSentinel(const Ray& r)
+{
+    return r.direction == v3(0, 0, 0) && r.origin == v3(0, 0, 0) && r.t == 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// BVH build — src/bounding_volume_hierarchy.cpp:22-194
+// ---------------------------------------------------------------------------
+inline void primBounds(const orc_scene* scene, const Primitive& p, V3& lo, V3& hi)
+{
+    if (!p.isSphere) {
+        const auto& vs = scene->meshes[p.meshIdx].vertices;
+        V3 p1 = vs[p.v1].position, p2 = vs[p.v2].position, p3 = vs[p.v3].position;
+        lo = v3(std::min({ p1.x, p2.x, p3.x }), std::min({ p1.y, p2.y, p3.y }), std::min({ p1.z, p2.z, p3.z }));
+        hi = v3(std::max({ p1.x, p2.x, p3.x }), std::max({ p1.y, p2.y, p3.y }), std::max({ p1.z, p2.z, p3.z }));
+    } else {
+        const Sphere& s = scene->spheres[p.sphereIdx];
+        lo = v3(s.center.x - s.radius, s.center.y - s.radius, s.center.z - s.radius);
+        hi = v3(s.center.x + s.radius, s.center.y + s.radius, s.center.z + s.radius);
+    }
+}
+
+// getBoundingBox (:22-62); returns false for an empty range
+bool getBoundingBox(const orc_bvh* b, size_t beg, size_t end, AABB& out)
+{
+    bool have = false;
+    for (; beg != end; beg++) {
+        V3 lo, hi;
+        primBounds(b->scene, b->primitives[beg], lo, hi);
+        AABB v = have ? out : AABB { lo, hi };
+        v.lower.x = std::min(v.lower.x, lo.x);
+        v.lower.y = std::min(v.lower.y, lo.y);
+        v.lower.z = std::min(v.lower.z, lo.z);
+        v.upper.x = std::max(v.upper.x, hi.x);
+        v.upper.y = std::max(v.upper.y, hi.y);
+        v.upper.z = std::max(v.upper.z, hi.z);
+        out = v;
+        have = true;
+    }
+    return have;
+}
+
+inline float boundingBoxSurfaceArea(const AABB& box)
+{
+    V3 l = box.upper - box.lower;
+    return 2 * (l.x * l.y + l.y * l.z + l.z * l.x);
+}
+
+inline float centerAxis(const Primitive& p, int axis) { return axis == 0 ? p.center.x : (axis == 1 ? p.center.y : p.center.z); }
+
+// splitStandard (:74-78)
+size_t splitStandard(orc_bvh* b, size_t beg, size_t end, size_t depth)
+{
+    size_t mid = beg + (end - beg) / 2;
+    int axis = (int)(depth % 3);
+    auto& prims = b->primitives;
+    std::nth_element(prims.begin() + beg, prims.begin() + mid, prims.begin() + end,
+        [axis](const Primitive& x, const Primitive& y) { return centerAxis(x, axis) < centerAxis(y, axis); });
+    return mid;
+}
+
+// calculateSplitCost (:80-88)
+float calculateSplitCost(orc_bvh* b, size_t beg, size_t end, size_t split)
+{
+    AABB boxLeft { v3(0, 0, 0), v3(0, 0, 0) }, boxRight { v3(0, 0, 0), v3(0, 0, 0) };
+    getBoundingBox(b, beg, split, boxLeft);
+    getBoundingBox(b, split, end, boxRight);
+    float areaLeft = boundingBoxSurfaceArea(boxLeft);
+    float areaRight = boundingBoxSurfaceArea(boxRight);
+    return areaLeft * (split - beg) + areaRight * (end - split);
+}
+
+// splitSAHBinning (:97-128)
+size_t splitSAHBinning(orc_bvh* b, size_t beg, size_t end, size_t /*depth*/)
+{
+    auto& prims = b->primitives;
+    size_t skip = std::max(1UL, (unsigned long)(end - beg) / (unsigned long)(NUM_OF_BINS));
+    size_t bestSplit = beg, bestAxis = 0; // (uninitialised in the reference; always set because end-beg >= 2)
+    float bestCost = FLT_MAX;
+    for (size_t axis = 0; axis < 3; axis++) {
+        int ax = (int)axis;
+        std::sort(prims.begin() + beg, prims.begin() + end,
+            [ax](const Primitive& x, const Primitive& y) { return centerAxis(x, ax) < centerAxis(y, ax); });
+        for (size_t split = beg + skip; split < end; split += skip) {
+            float cost = calculateSplitCost(b, beg, end, split);
+            if (cost < bestCost) {
+                bestSplit = split;
+                bestAxis = axis;
+                bestCost = cost;
+            }
+        }
+    }
+    int bax = (int)bestAxis;
+    std::sort(prims.begin() + beg, prims.begin() + end,
+        [bax](const Primitive& x, const Primitive& y) { return centerAxis(x, bax) < centerAxis(y, bax); });
+    return bestSplit;
+}
+
+// createBVH (:130-147)
+size_t createBVH(orc_bvh* b, size_t beg, size_t end, size_t depth)
+{
+    b->numLevels = std::max(b->numLevels, (int)depth + 1);
+    AABB aabb;
+    getBoundingBox(b, beg, end, aabb);
+    if (depth + 1 == MAX_DEPTH || beg + 1 == end) {
+        b->nodes.push_back(Node { aabb, 1, (uint32_t)depth, (uint32_t)beg, (uint32_t)end, 0, 0 });
+        b->numLeaves++;
+        return b->nodes.size() - 1;
+    }
+    size_t mid = b->sah ? splitSAHBinning(b, beg, end, depth) : splitStandard(b, beg, end, depth);
+    size_t left = createBVH(b, beg, mid, depth + 1);
+    size_t right = createBVH(b, mid, end, depth + 1);
+    b->nodes.push_back(Node { aabb, 0, (uint32_t)depth, (uint32_t)beg, (uint32_t)end, (uint32_t)left, (uint32_t)right });
+    return b->nodes.size() - 1;
+}
+
+// ---------------------------------------------------------------------------
+// Traversal + hit attributes — src/bounding_volume_hierarchy.cpp:272-427
+// ---------------------------------------------------------------------------
+
+// getIntersecting (:272-293): last accepted primitive wins
+int getIntersecting(const orc_bvh* b, size_t beg, size_t end, Ray& ray, HitInfo& hitInfo, Counters& c)
+{
+    int res = -1;
+    const orc_scene* scene = b->scene;
+    for (size_t i = beg; i < end; i++) {
+        const Primitive& prim = b->primitives[i];
+        bool hit;
+        if (!prim.isSphere) {
+            const auto& vs = scene->meshes[prim.meshIdx].vertices;
+            c.tri_tests++;
+            hit = intersectRayWithTriangle(vs[prim.v1].position, vs[prim.v2].position, vs[prim.v3].position, ray);
+        } else {
+            c.sphere_tests++;
+            hit = intersectRayWithSphere(scene->spheres[prim.sphereIdx], ray, hitInfo);
+        }
+        if (hit)
+            res = (int)i;
+    }
+    return res;
+}
+
+// BoundingVolumeHierarchy::intersect (:299-427). Returns the permuted index of
+// the final primitive (or -1) through *primPos.
+bool bvhIntersect(const orc_bvh* b, Ray& ray, HitInfo& hitInfo, const rt_features& f, Counters& c, int* primPos)
+{
+    c.rays++;
+    int prim = -1;
+    const orc_scene* scene = b->scene;
+    if (!f.enableAccelStructure) {
+        prim = getIntersecting(b, 0, b->primitives.size(), ray, hitInfo, c);
+    } else {
+        uint32_t stack[64];
+        int sp = 0;
+        stack[sp++] = b->root;
+        while (sp > 0) {
+            uint32_t parent = stack[--sp];
+            const Node& node = b->nodes[parent];
+            if (node.leaf == 1) {
+                int maybe = getIntersecting(b, node.beg, node.end, ray, hitInfo, c);
+                if (maybe >= 0)
+                    prim = maybe;
+            } else {
+                uint32_t left = node.left, right = node.right;
+                float rollBack = ray.t;
+                ray.t = FLT_MAX;
+                c.box_tests++;
+                bool leftBox = intersectRayWithBox(b->nodes[left].aabb, ray);
+                ray.t = FLT_MAX;
+                c.box_tests++;
+                bool rightBox = intersectRayWithBox(b->nodes[right].aabb, ray);
+                ray.t = rollBack;
+                if (leftBox)
+                    stack[sp++] = left;
+                if (rightBox)
+                    stack[sp++] = right;
+            }
+        }
+    }
+    if (primPos)
+        *primPos = prim;
+    if (prim < 0)
+        return false;
+    const Primitive& p = b->primitives[prim];
+    if (!p.isSphere) {
+        const Mesh& mesh = scene->meshes[p.meshIdx];
+        const Vertex &v1 = mesh.vertices[p.v1], &v2 = mesh.vertices[p.v2], &v3_ = mesh.vertices[p.v3];
+        if (f.enableNormalInterp) {
+            V3 bc = computeBarycentricCoord(v1.position, v2.position, v3_.position, ray.origin + ray.direction * ray.t);
+            V3 n = interpolateNormal(v1.normal, v2.normal, v3_.normal, bc);
+            if (dot(n, ray.direction) > 0)
+                n = -n;
+            hitInfo.normal = n;
+        } else {
+            hitInfo.normal = normalize(cross(v2.position - v1.position, v3_.position - v1.position));
+        }
+        Material material = mesh.material;
+        if (f.enableTextureMapping && material.texture >= 0) {
+            V3 bc = computeBarycentricCoord(v1.position, v2.position, v3_.position, ray.t * ray.direction + ray.origin);
+            V2 tc = interpolateTexCoord(v1.texCoord, v2.texCoord, v3_.texCoord, bc);
+            material.kd = acquireTexel(scene->textures[material.texture], tc, f);
+        }
+        hitInfo.material = material;
+    } else {
+        const Sphere& s = scene->spheres[p.sphereIdx];
+        V3 pt = ray.origin + ray.direction * ray.t;
+        hitInfo.normal = normalize(pt - s.center);
+        hitInfo.material = s.material;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Area-light RNG: counter-based replacement for rand() (src/light.cpp:21,32-33).
+// Same function as rt_rand31 in the C ABI (restated here so the oracle does not
+// link the product).
+// ---------------------------------------------------------------------------
+inline uint32_t pcg_hash(uint32_t v)
+{
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+inline uint32_t rand31(uint32_t seed, uint32_t pixel, uint32_t level, uint32_t light, uint32_t sample, uint32_t dim)
+{
+    uint32_t h = pcg_hash(seed ^ 0x9E3779B9u);
+    h = pcg_hash(h + pixel);
+    h = pcg_hash(h ^ ((level << 26) | (light << 18) | (sample << 1) | dim));
+    return h & 0x7fffffffu;
+}
+// (float)rand() / RAND_MAX, RAND_MAX = 2147483647 → 2147483648.0f
+inline float rand01(uint32_t r31) { return (float)(int32_t)r31 / 2147483648.0f; }
+
+struct TraceCtx {
+    const orc_bvh* bvh;
+    rt_features f;
+    rt_render_params params;
+    uint32_t pixel;
+    Counters* c;
+};
+
+// ---------------------------------------------------------------------------
+// src/light.cpp:19-73
+// ---------------------------------------------------------------------------
+float testVisibilityLightSample(TraceCtx& cx, V3 samplePos, Ray ray, HitInfo hitInfo)
+{
+    if (!cx.f.enableHardShadow && !cx.f.enableSoftShadow)
+        return 1.0f;
+    ray.t *= length(ray.direction);
+    ray.direction = normalize(ray.direction);
+    V3 p = ray.origin + ray.direction * (ray.t - .00001f);
+    Ray toLight;
+    toLight.origin = p;
+    toLight.direction = samplePos - p;
+    toLight.t = 1.0f;
+    cx.c->rays_shadow++;
+    bool hit = bvhIntersect(cx.bvh, toLight, hitInfo, cx.f, *cx.c, nullptr);
+    if (hit) {
+        if (!cx.f.enableTransparency)
+            return 0.0f;
+        return hitInfo.material.transparency;
+    }
+    return 1.0f;
+}
+
+// src/light.cpp:108-165
+V3 computeLightContribution(TraceCtx& cx, const Ray& ray, const HitInfo& hitInfo, uint32_t level)
+{
+    const orc_scene* scene = cx.bvh->scene;
+    if (!cx.f.enableShading)
+        return hitInfo.material.kd;
+    V3 result = v3(0, 0, 0);
+    for (size_t li = 0; li < scene->lights.size(); li++) {
+        const Light& L = scene->lights[li];
+        if (L.kind == RT_LIGHT_POINT) {
+            V3 color = computeShading(L.v[0], L.v[1], cx.f, ray, hitInfo);
+            float visibility = 1.0f;
+            if (cx.f.enableHardShadow)
+                visibility = testVisibilityLightSample(cx, L.v[0], ray, hitInfo);
+            result = result + color * visibility;
+        } else if (L.kind == RT_LIGHT_SEGMENT) {
+            if (cx.f.enableSoftShadow) {
+                V3 color = v3(0, 0, 0);
+                float sampleSize = (float)cx.params.segment_n;
+                for (int i = 0; (float)i < sampleSize; i++) {
+                    // sampleSegmentLight (:19-26)
+                    float r = rand01(rand31(cx.params.seed, cx.pixel, level, (uint32_t)li, (uint32_t)i, 0));
+                    float weight = ((float)i + r) / sampleSize;
+                    V3 position = (L.v[1] - L.v[0]) * weight + L.v[0];
+                    V3 colorOfLight = weight * L.v[3] + (1 - weight) * L.v[2];
+                    float visibility = testVisibilityLightSample(cx, position, ray, hitInfo);
+                    V3 thisColor = computeShading(position, colorOfLight, cx.f, ray, hitInfo);
+                    color = color + thisColor * visibility;
+                }
+                result = result + color / sampleSize;
+            }
+        } else {
+            if (cx.f.enableSoftShadow) {
+                V3 color = v3(0, 0, 0);
+                float sampleSizeA = (float)cx.params.parallelogram_n;
+                float sampleSizeB = (float)cx.params.parallelogram_n;
+                int n = cx.params.parallelogram_n;
+                for (int i = 0; (float)i < sampleSizeA; i++) {
+                    for (int k = 0; (float)k < sampleSizeB; k++) {
+                        // sampleParallelogramLight (:30-45)
+                        uint32_t s = (uint32_t)(i * n + k);
+                        float horRandom = rand01(rand31(cx.params.seed, cx.pixel, level, (uint32_t)li, s, 0));
+                        float verRandom = rand01(rand31(cx.params.seed, cx.pixel, level, (uint32_t)li, s, 1));
+                        float horWeight = ((float)i + horRandom) / sampleSizeA;
+                        float verWeight = ((float)k + verRandom) / sampleSizeB;
+                        V3 horVector = horWeight * L.v[1];
+                        V3 verVector = verWeight * L.v[2];
+                        V3 position = L.v[0] + horVector + verVector;
+                        V3 bottomColor = horWeight * L.v[4] + (1 - horWeight) * L.v[3];
+                        V3 topColor = horWeight * L.v[6] + (1 - horWeight) * L.v[5];
+                        V3 colorOfLight = verWeight * topColor + (1 - verWeight) * bottomColor;
+                        float visibility = testVisibilityLightSample(cx, position, ray, hitInfo);
+                        V3 thisColor = computeShading(position, colorOfLight, cx.f, ray, hitInfo);
+                        color = color + thisColor * visibility;
+                    }
+                }
+                result = result + color / (sampleSizeA * sampleSizeB);
+            }
+        }
+    }
+    return result;
+}
+
+// ---------------------------------------------------------------------------
+// src/render.cpp:27-155 — plain Whitted path. The glossy / enableTransparency
+// extras are outside the hot-path scope (callers reject those flags). The
+// `material.transparency != 1` branch of :122-130 IS restated (it runs
+// whenever enableRecursive is set, whatever enableTransparency says).
+// ---------------------------------------------------------------------------
+V3 recursiveRayTrace(TraceCtx& cx, Ray ray, int rayDepth, int rayDepthInitial, int guard)
+{
+    HitInfo hitInfo;
+    if (guard > 4096) // the reference would overflow its stack here
+        return v3(0, 0, 0);
+    uint32_t level = (uint32_t)(rayDepthInitial - rayDepth);
+    if (bvhIntersect(cx.bvh, ray, hitInfo, cx.f, *cx.c, nullptr)) {
+        V3 Lo = computeLightContribution(cx, ray, hitInfo, level);
+        Ray reflection = computeReflectionRay(ray, hitInfo);
+        if (!(isSentinel(reflection) || rayDepth < 1)) {
+            if (cx.f.enableRecursive) {
+                cx.c->rays_reflect++;
+                Lo = Lo + recursiveRayTrace(cx, reflection, rayDepth - 1, rayDepthInitial, guard + 1);
+            }
+        }
+        if (cx.f.enableRecursive) {
+            Ray reflection2 = computeReflectionRay(ray, hitInfo);
+            if (!isSentinel(reflection2)) {
+                if (rayDepth > 0) {
+                    cx.c->rays_reflect++;
+                    Lo = Lo + recursiveRayTrace(cx, reflection2, rayDepth - 1, rayDepthInitial, guard + 1);
+                }
+            }
+            if (hitInfo.material.transparency != 1) {
+                cx.c->rays_reflect++;
+                V3 vec = recursiveRayTrace(cx, reflection2, rayDepth - 1, rayDepthInitial, guard + 1);
+                V3 v = hitInfo.material.transparency * vec + (1 - hitInfo.material.transparency) * Lo;
+                // (:125-127: an extra bvh.intersect on a scratch HitInfo, result unused)
+                HitInfo h;
+                h.normal = hitInfo.normal;
+                bvhIntersect(cx.bvh, reflection2, h, cx.f, *cx.c, nullptr);
+                return v;
+            }
+        }
+        return Lo;
+    }
+    return v3(0, 0, 0);
+}
+
+// framework/src/trackball.cpp:101-110 with the quaternion / half extents
+// precomputed (they depend on the camera only).
+inline V3 quatRotate(const float q[4], V3 v)
+{
+    // glm/detail/type_quat.inl:347-354
+    V3 QuatVector = v3(q[1], q[2], q[3]);
+    V3 uv = cross(QuatVector, v);
+    V3 uuv = cross(QuatVector, uv);
+    return v + ((uv * q[0]) + uuv) * 2.0f;
+}
+inline Ray generateRay(const rt_camera& cam, float px, float py)
+{
+    V3 cameraSpaceDirection = normalize(v3(-px * cam.half_w, py * cam.half_h, 1.0f));
+    Ray ray;
+    ray.origin = v3(cam.origin);
+    ray.direction = quatRotate(cam.quat, cameraSpaceDirection);
+    ray.t = FLT_MAX;
+    return ray;
+}
+
+void addCounters(rt_counters* out, const Counters& c)
+{
+    if (!out)
+        return;
+    out->rays += c.rays;
+    out->rays_primary += c.rays_primary;
+    out->rays_shadow += c.rays_shadow;
+    out->rays_reflect += c.rays_reflect;
+    out->rays_ref_equiv += c.rays;
+    out->box_tests += c.box_tests;
+    out->tri_tests += c.tri_tests;
+    out->sphere_tests += c.sphere_tests;
+}
+
+Material toMaterial(const rt_material& m)
+{
+    return Material { v3(m.kd), v3(m.ks), m.shininess, m.transparency, m.texture };
+}
+void fromMaterial(const Material& m, rt_material& o)
+{
+    o.kd[0] = m.kd.x, o.kd[1] = m.kd.y, o.kd[2] = m.kd.z;
+    o.ks[0] = m.ks.x, o.ks[1] = m.ks.y, o.ks[2] = m.ks.z;
+    o.shininess = m.shininess;
+    o.transparency = m.transparency;
+    o.texture = m.texture;
+}
+
+} // namespace
+
+extern "C" {
+
+orc_scene* orc_scene_create(const rt_scene_desc* d)
+{
+    orc_scene* s = new orc_scene;
+    uint32_t base = 0;
+    for (uint32_t m = 0; m < d->n_meshes; m++) {
+        const rt_mesh_desc& md = d->meshes[m];
+        Mesh mesh;
+        mesh.vertices.resize(md.n_vertices);
+        for (uint32_t i = 0; i < md.n_vertices; i++) {
+            mesh.vertices[i].position = v3(md.positions + 3 * i);
+            mesh.vertices[i].normal = md.normals ? v3(md.normals + 3 * i) : v3(0, 0, 0);
+            mesh.vertices[i].texCoord = md.texcoords ? V2 { md.texcoords[2 * i], md.texcoords[2 * i + 1] } : V2 { 0, 0 };
+        }
+        mesh.triangles.assign(md.triangles, md.triangles + 3 * (size_t)md.n_triangles);
+        mesh.material = toMaterial(md.material);
+        s->meshPrimBase.push_back(base);
+        base += md.n_triangles;
+        s->meshes.push_back(std::move(mesh));
+    }
+    for (uint32_t i = 0; i < d->n_spheres; i++)
+        s->spheres.push_back(Sphere { v3(d->spheres[i].center), d->spheres[i].radius, toMaterial(d->spheres[i].material) });
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        Light L;
+        L.kind = d->lights[i].kind;
+        for (int k = 0; k < 7; k++)
+            L.v[k] = v3(d->lights[i].v[k]);
+        s->lights.push_back(L);
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        Image im;
+        im.width = d->textures[i].width;
+        im.height = d->textures[i].height;
+        im.pixels.resize((size_t)im.width * im.height);
+        for (size_t k = 0; k < im.pixels.size(); k++)
+            im.pixels[k] = v3(d->textures[i].pixels + 3 * k);
+        s->textures.push_back(std::move(im));
+    }
+    return s;
+}
+void orc_scene_destroy(orc_scene* s) { delete s; }
+
+// BoundingVolumeHierarchy::BoundingVolumeHierarchy (:149-194)
+orc_bvh* orc_bvh_build(orc_scene* scene, const rt_features* f)
+{
+    orc_bvh* b = new orc_bvh;
+    b->scene = scene;
+    b->sah = f->enableBvhSahBinning != 0;
+    int32_t id = 0;
+    for (uint32_t m = 0; m < scene->meshes.size(); m++) {
+        const Mesh& mesh = scene->meshes[m];
+        for (size_t t = 0; t < mesh.triangles.size() / 3; t++) {
+            uint32_t a = mesh.triangles[3 * t], bq = mesh.triangles[3 * t + 1], c = mesh.triangles[3 * t + 2];
+            // triangleCenter (:70-72): (a + b + c) / 3.f
+            V3 center = (mesh.vertices[a].position + mesh.vertices[bq].position + mesh.vertices[c].position) / 3.f;
+            b->primitives.push_back(Primitive { 0, m, a, bq, c, 0, center, id++ });
+        }
+    }
+    for (uint32_t si = 0; si < scene->spheres.size(); si++)
+        b->primitives.push_back(Primitive { 1, 0, 0, 0, 0, si, scene->spheres[si].center, id++ });
+    if (b->primitives.empty()) { // the reference throws bad_optional_access (:132)
+        delete b;
+        return nullptr;
+    }
+    b->root = (uint32_t)createBVH(b, 0, b->primitives.size(), 0);
+    return b;
+}
+void orc_bvh_destroy(orc_bvh* b) { delete b; }
+int orc_bvh_num_levels(const orc_bvh* b) { return b->numLevels; }
+int orc_bvh_num_leaves(const orc_bvh* b) { return b->numLeaves; }
+int orc_bvh_num_nodes(const orc_bvh* b) { return (int)b->nodes.size(); }
+int orc_bvh_num_prims(const orc_bvh* b) { return (int)b->primitives.size(); }
+
+// same shape as rt_bvh_export
+void orc_bvh_export(const orc_bvh* b, float* node_aabb, int32_t* node_meta, int32_t* prim_order)
+{
+    for (size_t i = 0; i < b->nodes.size(); i++) {
+        const Node& n = b->nodes[i];
+        if (node_aabb) {
+            float* a = node_aabb + 6 * i;
+            a[0] = n.aabb.lower.x, a[1] = n.aabb.lower.y, a[2] = n.aabb.lower.z;
+            a[3] = n.aabb.upper.x, a[4] = n.aabb.upper.y, a[5] = n.aabb.upper.z;
+        }
+        if (node_meta) {
+            int32_t* m = node_meta + 6 * i;
+            m[0] = n.leaf, m[1] = (int32_t)n.depth, m[2] = (int32_t)n.beg, m[3] = (int32_t)n.end;
+            m[4] = n.leaf ? -1 : (int32_t)n.left, m[5] = n.leaf ? -1 : (int32_t)n.right;
+        }
+    }
+    if (prim_order)
+        for (size_t i = 0; i < b->primitives.size(); i++)
+            prim_order[i] = b->primitives[i].id;
+}
+
+// Trackball ctor + setCamera + position() (framework/src/trackball.cpp:23-31,64-74)
+void orc_camera_from_trackball(float fovy, float aspect, const float look_at[3], float distance,
+    const float rot[3], rt_camera* out)
+{
+    out->half_h = std::tan(fovy / 2.0f);
+    out->half_w = aspect * out->half_h;
+    // glm::quat(vec3 eulerAngle) glm/detail/type_quat.inl:208-217
+    float cx = std::cos(rot[0] * 0.5f), cy = std::cos(rot[1] * 0.5f), cz = std::cos(rot[2] * 0.5f);
+    float sx = std::sin(rot[0] * 0.5f), sy = std::sin(rot[1] * 0.5f), sz = std::sin(rot[2] * 0.5f);
+    out->quat[0] = cx * cy * cz + sx * sy * sz;
+    out->quat[1] = sx * cy * cz - cx * sy * sz;
+    out->quat[2] = cx * sy * cz + sx * cy * sz;
+    out->quat[3] = cx * cy * sz - sx * sy * cz;
+    V3 p = v3(look_at) + quatRotate(out->quat, v3(0, 0, -distance));
+    out->origin[0] = p.x, out->origin[1] = p.y, out->origin[2] = p.z;
+}
+
+void orc_generate_ray(const rt_camera* cam, float ndc_x, float ndc_y, rt_ray* out)
+{
+    Ray r = generateRay(*cam, ndc_x, ndc_y);
+    out->origin[0] = r.origin.x, out->origin[1] = r.origin.y, out->origin[2] = r.origin.z;
+    out->direction[0] = r.direction.x, out->direction[1] = r.direction.y, out->direction[2] = r.direction.z;
+    out->t = r.t;
+}
+
+// ≙ BvhInterface::intersect on a batch
+void orc_intersect_batch(const orc_bvh* b, rt_ray* rays, uint32_t n, const rt_features* f, rt_hit* hits,
+    rt_counters* counters)
+{
+    Counters c;
+    for (uint32_t i = 0; i < n; i++) {
+        Ray r;
+        r.origin = v3(rays[i].origin);
+        r.direction = v3(rays[i].direction);
+        r.t = rays[i].t;
+        HitInfo h;
+        int pos = -1;
+        bool hit = bvhIntersect(b, r, h, *f, c, &pos);
+        rays[i].t = r.t;
+        if (hits) {
+            rt_hit& o = hits[i];
+            memset(&o, 0, sizeof(o));
+            o.hit = hit ? 1 : 0;
+            o.prim = hit ? b->primitives[pos].id : -1;
+            o.t = r.t;
+            o.normal[0] = h.normal.x, o.normal[1] = h.normal.y, o.normal[2] = h.normal.z;
+            fromMaterial(h.material, o.material);
+        }
+    }
+    addCounters(counters, c);
+}
+
+// ≙ getFinalColor on a batch
+void orc_trace_batch(const orc_bvh* b, const rt_ray* rays, uint32_t n, const uint32_t* pixel_ids,
+    const rt_features* f, const rt_render_params* params, float* rgb, rt_counters* counters)
+{
+    Counters c;
+    TraceCtx cx { b, *f, *params, 0, &c };
+    for (uint32_t i = 0; i < n; i++) {
+        Ray r;
+        r.origin = v3(rays[i].origin);
+        r.direction = v3(rays[i].direction);
+        r.t = rays[i].t;
+        cx.pixel = pixel_ids ? pixel_ids[i] : i;
+        c.rays_primary++;
+        V3 col = recursiveRayTrace(cx, r, params->depth, params->depth, 0);
+        rgb[3 * i] = col.x, rgb[3 * i + 1] = col.y, rgb[3 * i + 2] = col.z;
+    }
+    addCounters(counters, c);
+}
+
+// ≙ renderRayTracing (src/render.cpp:273-329, plain path) over rows [y0,y1),
+// explicit depth. rgb: full W*H*3 frame, row-flipped (src/screen.cpp:41-47).
+// t_bits / prim (optional, W*H, same flip): primary-ray hit records.
+// threads <= 0 → all OpenMP threads.
+void orc_render(const orc_bvh* b, const rt_camera* cam, const rt_features* f, const rt_render_params* params,
+    int32_t W, int32_t H, int32_t y0, int32_t y1, float* rgb, uint32_t* t_bits, int32_t* prim,
+    rt_counters* counters, int threads)
+{
+#ifdef _OPENMP
+    int nthreads = threads > 0 ? threads : omp_get_max_threads();
+#else
+    int nthreads = 1;
+    (void)threads;
+#endif
+    std::vector<Counters> cs((size_t)nthreads);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(guided) num_threads(nthreads)
+#endif
+    for (int y = y0; y < y1; y++) {
+#ifdef _OPENMP
+        Counters& c = cs[(size_t)omp_get_thread_num()];
+#else
+        Counters& c = cs[0];
+#endif
+        TraceCtx cx { b, *f, *params, 0, &c };
+        for (int x = 0; x != W; x++) {
+            float px = float(x) / float(W) * 2.0f - 1.0f;
+            float py = float(y) / float(H) * 2.0f - 1.0f;
+            Ray cameraRay = generateRay(*cam, px, py);
+            size_t idx = (size_t)(H - 1 - y) * W + x; // Screen::setPixel
+            cx.pixel = (uint32_t)(y * W + x);
+            if (t_bits || prim) {
+                Ray r = cameraRay;
+                HitInfo h;
+                Counters scratch;
+                int pos = -1;
+                bool hit = bvhIntersect(b, r, h, *f, scratch, &pos);
+                if (t_bits)
+                    memcpy(&t_bits[idx], &r.t, 4);
+                if (prim)
+                    prim[idx] = hit ? b->primitives[pos].id : -1;
+            }
+            if (rgb) {
+                c.rays_primary++;
+                V3 colorSum = v3(0.f, 0.f, 0.f);
+                colorSum = colorSum + recursiveRayTrace(cx, cameraRay, params->depth, params->depth, 0);
+                V3 finalColor = colorSum / float(1);
+                rgb[3 * idx] = finalColor.x, rgb[3 * idx + 1] = finalColor.y, rgb[3 * idx + 2] = finalColor.z;
+            }
+        }
+    }
+    Counters total;
+    for (const Counters& c : cs) {
+        total.rays += c.rays, total.rays_primary += c.rays_primary, total.rays_shadow += c.rays_shadow;
+        total.rays_reflect += c.rays_reflect, total.box_tests += c.box_tests, total.tri_tests += c.tri_tests;
+        total.sphere_tests += c.sphere_tests;
+    }
+    addCounters(counters, total);
+}
+
+// Single-function probes used to pin the restatement against oracle/_ref.
+void orc_compute_shading(const float lightPos[3], const float lightColor[3], const rt_features* f, const rt_ray* ray,
+    const float normal[3], const rt_material* m, float out[3])
+{
+    Ray r;
+    r.origin = v3(ray->origin), r.direction = v3(ray->direction), r.t = ray->t;
+    HitInfo h;
+    h.normal = v3(normal);
+    h.material = toMaterial(*m);
+    V3 c = computeShading(v3(lightPos), v3(lightColor), *f, r, h);
+    out[0] = c.x, out[1] = c.y, out[2] = c.z;
+}
+void orc_compute_reflection_ray(const rt_ray* ray, const float normal[3], const rt_material* m, rt_ray* out)
+{
+    Ray r;
+    r.origin = v3(ray->origin), r.direction = v3(ray->direction), r.t = ray->t;
+    HitInfo h;
+    h.normal = v3(normal);
+    h.material = toMaterial(*m);
+    Ray o = computeReflectionRay(r, h);
+    out->origin[0] = o.origin.x, out->origin[1] = o.origin.y, out->origin[2] = o.origin.z;
+    out->direction[0] = o.direction.x, out->direction[1] = o.direction.y, out->direction[2] = o.direction.z;
+    out->t = o.t;
+}
+void orc_barycentric(const float v0[3], const float v1[3], const float v2[3], const float p[3], float out[3])
+{
+    V3 b = computeBarycentricCoord(v3(v0), v3(v1), v3(v2), v3(p));
+    out[0] = b.x, out[1] = b.y, out[2] = b.z;
+}
+void orc_interpolate_normal(const float n0[3], const float n1[3], const float n2[3], const float bc[3], float out[3])
+{
+    V3 n = interpolateNormal(v3(n0), v3(n1), v3(n2), v3(bc));
+    out[0] = n.x, out[1] = n.y, out[2] = n.z;
+}
+void orc_interpolate_texcoord(const float t0[2], const float t1[2], const float t2[2], const float bc[3], float out[2])
+{
+    V2 t = interpolateTexCoord(V2 { t0[0], t0[1] }, V2 { t1[0], t1[1] }, V2 { t2[0], t2[1] }, v3(bc));
+    out[0] = t.x, out[1] = t.y;
+}
+void orc_acquire_texel(const orc_scene* s, int texture, const float tc[2], const rt_features* f, float out[3])
+{
+    V3 c = acquireTexel(s->textures[texture], V2 { tc[0], tc[1] }, *f);
+    out[0] = c.x, out[1] = c.y, out[2] = c.z;
+}
+// primitive-test probes (Appendix A)
+int orc_intersect_triangle(const float v0[3], const float v1[3], const float v2[3], rt_ray* ray)
+{
+    Ray r;
+    r.origin = v3(ray->origin), r.direction = v3(ray->direction), r.t = ray->t;
+    bool h = intersectRayWithTriangle(v3(v0), v3(v1), v3(v2), r);
+    ray->t = r.t;
+    return h;
+}
+int orc_intersect_box(const float lower[3], const float upper[3], rt_ray* ray)
+{
+    Ray r;
+    r.origin = v3(ray->origin), r.direction = v3(ray->direction), r.t = ray->t;
+    AABB b { v3(lower), v3(upper) };
+    bool h = intersectRayWithBox(b, r);
+    ray->t = r.t;
+    return h;
+}
+int orc_intersect_sphere(const float center[3], float radius, rt_ray* ray, float normal_out[3])
+{
+    Ray r;
+    r.origin = v3(ray->origin), r.direction = v3(ray->direction), r.t = ray->t;
+    Sphere s { v3(center), radius, Material { v3(0, 0, 0), v3(0, 0, 0), 1, 1, -1 } };
+    HitInfo h;
+    bool hit = intersectRayWithSphere(s, r, h);
+    ray->t = r.t;
+    if (normal_out)
+        normal_out[0] = h.normal.x, normal_out[1] = h.normal.y, normal_out[2] = h.normal.z;
+    return hit;
+}
+uint32_t orc_rand31(uint32_t seed, uint32_t pixel, uint32_t level, uint32_t light, uint32_t sample, uint32_t dim)
+{
+    return rand31(seed, pixel, level, light, sample, dim);
+}
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+} // extern "C"
