@@ -1,0 +1,218 @@
+"""ctypes binding of the C ABI (include/rt_whitted.h → csrc/librt_whitted.so).
+
+This is plumbing over the shared library, not a second implementation: every
+method forwards to one `rt_*` entry point. There is no CPU fallback — if the
+library is missing it is built with hipcc, and if no HIP device is usable the
+compute calls raise `RtError` (RT_ERR_DEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import abi
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "librt_whitted.so"
+
+EXPORTS = [
+    "rt_last_error", "rt_device_info", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
+    "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
+    "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
+    "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips",
+    "rt_rand31",
+]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"rt error {code}: {message}")
+        self.code = code
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile csrc/ for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")) + list(CSRC.glob("*.h")) + \
+        [CSRC.parent.parent / "include" / "rt_whitted.h"]
+    stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
+    if force or stale:
+        r = subprocess.run(["make", "-C", str(CSRC), "librt_whitted.so"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc build of librt_whitted.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def _f3(x):
+    return (C.c_float * 3)(*[float(v) for v in x])
+
+
+class Scene:
+    def __init__(self, lib: "Library", data: abi.SceneData):
+        self.lib, self.data = lib, data
+        holder = abi.SceneDescHolder(data)
+        h = C.c_void_p()
+        lib._check(lib.c.rt_scene_create(C.byref(holder.desc), C.byref(h)))
+        self.handle = h
+
+    def update_lights(self, lights: Sequence[abi.LightData]):
+        arr = abi.lights_to_c(lights)
+        self.lib._check(self.lib.c.rt_scene_update_lights(self.handle, arr, len(lights)))
+
+    def close(self):
+        if self.handle:
+            self.lib.c.rt_scene_destroy(self.handle)
+            self.handle = None
+
+
+class Bvh:
+    """≙ BvhInterface (src/bvh_interface.h:12-49)."""
+
+    def __init__(self, lib: "Library", scene: Scene, features: abi.Features):
+        self.lib, self.scene = lib, scene
+        h = C.c_void_p()
+        lib._check(lib.c.rt_bvh_build(scene.handle, C.byref(features), C.byref(h)))
+        self.handle = h
+
+    num_levels = property(lambda s: s.lib.c.rt_bvh_num_levels(s.handle))
+    num_leaves = property(lambda s: s.lib.c.rt_bvh_num_leaves(s.handle))
+    num_nodes = property(lambda s: s.lib.c.rt_bvh_num_nodes(s.handle))
+    num_prims = property(lambda s: s.lib.c.rt_bvh_num_prims(s.handle))
+
+    def export(self):
+        n, p = self.num_nodes, self.num_prims
+        aabb = np.zeros((n, 6), np.float32)
+        meta = np.zeros((n, 6), np.int32)
+        order = np.zeros(p, np.int32)
+        self.lib._check(self.lib.c.rt_bvh_export(self.handle, aabb.ctypes.data, meta.ctypes.data, order.ctypes.data))
+        return aabb, meta, order
+
+    def close(self):
+        if self.handle:
+            self.lib.c.rt_bvh_destroy(self.handle)
+            self.handle = None
+
+
+class Library:
+    def __init__(self, build: bool = True):
+        path = build_library() if build else LIB_PATH
+        self.c = C.CDLL(str(path))
+        c = self.c
+        c.rt_last_error.restype = C.c_char_p
+        c.rt_device_info.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        c.rt_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
+        c.rt_scene_destroy.argtypes = [C.c_void_p]
+        c.rt_scene_update_lights.argtypes = [C.c_void_p, C.POINTER(abi.LightDesc), C.c_uint32]
+        c.rt_bvh_build.argtypes = [C.c_void_p, C.POINTER(abi.Features), C.POINTER(C.c_void_p)]
+        c.rt_bvh_destroy.argtypes = [C.c_void_p]
+        for n in ("rt_bvh_num_levels", "rt_bvh_num_leaves", "rt_bvh_num_nodes", "rt_bvh_num_prims"):
+            getattr(c, n).argtypes = [C.c_void_p]
+        c.rt_bvh_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        c.rt_camera_from_trackball.argtypes = [C.c_float, C.c_float, C.c_float * 3, C.c_float, C.c_float * 3,
+                                               C.POINTER(abi.Camera)]
+        c.rt_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Features),
+                                C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                C.POINTER(abi.Counters)]
+        c.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Features),
+                                       C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        c.rt_render_hits.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Features), C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_void_p]
+        c.rt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(abi.Features),
+                                     C.POINTER(abi.RenderParams), C.c_void_p, C.POINTER(abi.Counters)]
+        c.rt_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(abi.Features), C.c_void_p,
+                                         C.POINTER(abi.Counters)]
+        c.rt_deinterleave_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_void_p]
+        c.rt_rand31.restype = C.c_uint32
+        c.rt_rand31.argtypes = [C.c_uint32] * 6
+
+    # -- errors
+    def _check(self, code: int):
+        if code != abi.RT_OK:
+            raise RtError(code, (self.c.rt_last_error() or b"").decode())
+
+    def device_info(self):
+        n = C.c_int()
+        buf = C.create_string_buffer(256)
+        self._check(self.c.rt_device_info(C.byref(n), buf, 256))
+        return n.value, buf.value.decode()
+
+    def set_device(self, device: int):
+        self._check(self.c.rt_set_device(device))
+
+    # -- objects
+    def scene(self, data: abi.SceneData) -> Scene:
+        return Scene(self, data)
+
+    def bvh(self, scene: Scene, features: abi.Features) -> Bvh:
+        return Bvh(self, scene, features)
+
+    def camera(self, fovy, aspect, look_at, distance, rotation) -> abi.Camera:
+        cam = abi.Camera()
+        self._check(self.c.rt_camera_from_trackball(fovy, aspect, _f3(look_at), distance, _f3(rotation),
+                                                    C.byref(cam)))
+        return cam
+
+    # -- ≙ renderRayTracing (host framebuffer)
+    def render(self, bvh: Bvh, cam, features, params, width, height, rows=None, count=False):
+        y0, y1 = rows if rows is not None else (0, height)
+        rgb = np.zeros((height, width, 3), np.float32)
+        cnt = abi.Counters() if count else None
+        self._check(self.c.rt_render(bvh.handle, C.byref(cam), C.byref(features), C.byref(params), width, height,
+                                     y0, y1, rgb.ctypes.data, C.byref(cnt) if count else None))
+        return (rgb, cnt) if count else rgb
+
+    # -- same, framebuffer in HBM (pointers are ints, e.g. torch.Tensor.data_ptr())
+    def render_device(self, bvh: Bvh, cam, features, params, width, height, rgb_ptr: int, rows=None, packed=False,
+                      counters_ptr: int = 0, stream: int = 0):
+        rows_arr = None
+        n_rows = height
+        if rows is not None:
+            rows_arr = np.ascontiguousarray(rows, np.int32)
+            n_rows = len(rows_arr)
+        self._check(self.c.rt_render_device(
+            bvh.handle, C.byref(cam), C.byref(features), C.byref(params), width, height,
+            rows_arr.ctypes.data if rows_arr is not None else None, n_rows, 1 if packed else 0,
+            C.c_void_p(rgb_ptr), C.c_void_p(counters_ptr) if counters_ptr else None,
+            C.c_void_p(stream) if stream else None))
+
+    def render_hits(self, bvh: Bvh, cam, features, width, height):
+        tb = np.zeros((height, width), np.uint32)
+        pr = np.zeros((height, width), np.int32)
+        self._check(self.c.rt_render_hits(bvh.handle, C.byref(cam), C.byref(features), width, height,
+                                          tb.ctypes.data, pr.ctypes.data))
+        return tb, pr
+
+    # -- ≙ getFinalColor on a batch
+    def trace_batch(self, bvh: Bvh, rays: np.ndarray, features, params, pixel_ids=None, count=False):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        rgb = np.zeros((len(rays), 3), np.float32)
+        pid = None
+        if pixel_ids is not None:
+            pixel_ids = np.ascontiguousarray(pixel_ids, np.uint32)
+            pid = pixel_ids.ctypes.data
+        cnt = abi.Counters() if count else None
+        self._check(self.c.rt_trace_batch(bvh.handle, rays.ctypes.data, len(rays), pid, C.byref(features),
+                                          C.byref(params), rgb.ctypes.data, C.byref(cnt) if count else None))
+        return (rgb, cnt) if count else rgb
+
+    # -- ≙ BvhInterface::intersect on a batch
+    def intersect_batch(self, bvh: Bvh, rays: np.ndarray, features, count=False):
+        rays = np.ascontiguousarray(rays.copy(), dtype=abi.RAY_DTYPE)
+        hits = np.zeros(len(rays), abi.HIT_DTYPE)
+        cnt = abi.Counters() if count else None
+        self._check(self.c.rt_intersect_batch(bvh.handle, rays.ctypes.data, len(rays), C.byref(features),
+                                              hits.ctypes.data, C.byref(cnt) if count else None))
+        return (rays, hits, cnt) if count else (rays, hits)
+
+    def deinterleave_strips(self, gathered_ptr: int, frame_ptr: int, width, height, strip_rows, n_ranks,
+                            stream: int = 0):
+        self._check(self.c.rt_deinterleave_strips(C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), width, height,
+                                                  strip_rows, n_ranks, C.c_void_p(stream) if stream else None))
+
+    def rand31(self, seed, pixel, level, light, sample, dim) -> int:
+        return int(self.c.rt_rand31(seed, pixel, level, light, sample, dim))

@@ -1,0 +1,655 @@
+// rt_capi.hip — the C ABI of include/rt_whitted.h on top of the HIP kernels.
+//
+// No CPU fallback exists anywhere in this library: every compute entry point
+// needs a HIP device and returns RT_ERR_DEVICE (with rt_last_error()) otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_whitted.h"
+#include "host_scene.h"
+#include "rt_kernels.h"
+#include "rt_shade.h"
+
+namespace {
+
+thread_local std::string g_error;
+// host-output entry points share the default-stream scratch of a bvh: one at a time
+std::mutex g_host_call_mu;
+
+int fail(int code, const std::string& msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr, n = 0;
+    }
+    hipError_t reserve(size_t count)
+    {
+        if (count <= n)
+            return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess)
+            n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v)
+    {
+        hipError_t e = reserve(std::max<size_t>(v.size(), 1));
+        if (e != hipSuccess || v.empty())
+            return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+// per-(bvh, stream) scratch: level colours, per-item state, two ray queues
+struct Scratch {
+    DevBuf<float> direct;
+    DevBuf<uint32_t> state;
+    DevBuf<float> qray[2];
+    DevBuf<uint32_t> qitem[2], qpixel[2];
+    DevBuf<uint32_t> counts;
+    DevBuf<int32_t> rows;
+    std::vector<int32_t> rows_host;
+    DevBuf<float> frame;      // device frame for host-output calls
+    DevBuf<float> in_ray, in_t; // uploaded user rays
+    DevBuf<uint32_t> in_pixel;
+    DevBuf<rt_hit> hits;
+    DevBuf<uint32_t> t_bits;
+    DevBuf<int32_t> prim;
+    DevBuf<rt_counters> counters;
+};
+
+} // namespace
+
+struct rt_scene {
+    int device = 0;
+    rt::HostScene host;
+    DevBuf<float> vnormal, vtexcoord, texels;
+    DevBuf<uint32_t> tri_vidx;
+    DevBuf<rt::MaterialRec> materials;
+    DevBuf<rt::TextureRec> textures;
+    DevBuf<rt::LightRec> lights;
+    uint32_t n_lights = 0;
+    std::mutex mu;
+};
+
+struct rt_bvh {
+    rt_scene* scene = nullptr;
+    rt::HostBvh host;
+    DevBuf<rt::NodePair> nodes;
+    DevBuf<rt::PrimRecord> prims;
+    std::mutex mu;
+    std::map<void*, std::unique_ptr<Scratch>> scratch; // keyed by stream
+    Scratch& scratch_for(void* stream)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto& s = scratch[stream];
+        if (!s)
+            s.reset(new Scratch);
+        return *s;
+    }
+    rt::SceneView view() const
+    {
+        rt::SceneView v;
+        v.nodes = nodes.p;
+        v.prims = prims.p;
+        v.tri_vidx = scene->tri_vidx.p;
+        v.vnormal = scene->vnormal.p;
+        v.vtexcoord = scene->vtexcoord.p;
+        v.materials = scene->materials.p;
+        v.textures = scene->textures.p;
+        v.texels = scene->texels.p;
+        v.lights = scene->lights.p;
+        v.n_lights = scene->n_lights;
+        v.root_ref = host.root_ref;
+        v.root_cnt = host.root_cnt;
+        v.n_prims = (uint32_t)host.records.size();
+        return v;
+    }
+};
+
+namespace {
+
+uint32_t feature_flags(const rt_features& f)
+{
+    uint32_t fl = 0;
+    if (f.enableShading) fl |= rt::F_SHADING;
+    if (f.enableRecursive) fl |= rt::F_RECURSIVE;
+    if (f.enableHardShadow) fl |= rt::F_HARD_SHADOW;
+    if (f.enableSoftShadow) fl |= rt::F_SOFT_SHADOW;
+    if (f.enableNormalInterp) fl |= rt::F_NORMAL_INTERP;
+    if (f.enableTextureMapping) fl |= rt::F_TEXTURE;
+    if (f.enableAccelStructure) fl |= rt::F_ACCEL;
+    if (f.enableBilinearTextureFiltering) fl |= rt::F_BILINEAR;
+    return fl;
+}
+
+// Flags outside the hot-path scope fail loudly instead of rendering something else.
+// (enableEnvironmentMapping / enableMotionBlur / enableMipmapTextureFiltering are
+// never read by the reference's render path and are ignored like it does.)
+int check_features(const rt_features* f, const rt_bvh* bvh)
+{
+    if (!f)
+        return fail(RT_ERR_INVALID, "features == NULL");
+    if (f->enableBloomEffect)
+        return fail(RT_ERR_UNSUPPORTED, "enableBloomEffect (render.cpp:158-210) is outside the hot-path scope");
+    if (f->enableMultipleRaysPerPixel)
+        return fail(RT_ERR_UNSUPPORTED, "enableMultipleRaysPerPixel (render.cpp:295-303) is outside the hot-path scope");
+    if (f->enableDepthOfField)
+        return fail(RT_ERR_UNSUPPORTED, "enableDepthOfField (render.cpp:305-314) is outside the hot-path scope");
+    if (f->enableGlossyReflection)
+        return fail(RT_ERR_UNSUPPORTED, "enableGlossyReflection (render.cpp:56-99) is outside the hot-path scope");
+    if (f->enableTransparency)
+        return fail(RT_ERR_UNSUPPORTED, "enableTransparency (render.cpp:36-49,108-111) is outside the hot-path scope");
+    if (f->enableRecursive && bvh->scene->host.any_non_opaque)
+        return fail(RT_ERR_UNSUPPORTED,
+            "enableRecursive with a material whose transparency != 1 takes the un-depth-limited branch of "
+            "render.cpp:122-130, which is outside the hot-path scope");
+    return RT_OK;
+}
+
+int check_params(const rt_render_params* p)
+{
+    if (!p)
+        return fail(RT_ERR_INVALID, "params == NULL");
+    if (p->depth < 0 || p->depth > 62)
+        return fail(RT_ERR_INVALID, "depth must be in [0, 62]");
+    if (p->parallelogram_n < 0 || p->parallelogram_n > 181 || p->segment_n < 0 || p->segment_n > 32767)
+        return fail(RT_ERR_INVALID, "light sample counts out of range");
+    return RT_OK;
+}
+
+rt::CameraArgs camera_args(const rt_camera& c, int32_t w, int32_t h)
+{
+    rt::CameraArgs a;
+    memcpy(a.origin, c.origin, 12);
+    memcpy(a.quat, c.quat, 16);
+    a.half_w = c.half_w, a.half_h = c.half_h;
+    a.width = w, a.height = h;
+    a.rows = nullptr, a.row0 = 0, a.n_rows = h;
+    return a;
+}
+
+// Enqueue the whole flattened recursion for n_items rays on `stream`:
+// level kernels, then the fold into fold.out.
+int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_render_params& p, int32_t source,
+    const rt::CameraArgs& cam, const rt::RaySoA& user_rays, uint32_t n_items, rt::FoldArgs fold,
+    rt_counters* counters_dev, hipStream_t stream)
+{
+    const uint32_t flags = feature_flags(f);
+    const int32_t n_levels = (flags & rt::F_RECURSIVE) ? p.depth + 1 : 1;
+    HIP_TRY(sc.direct.reserve((size_t)n_levels * n_items * 3));
+    HIP_TRY(sc.state.reserve(n_items));
+    HIP_TRY(sc.counts.reserve((size_t)n_levels + 1));
+    if (n_levels > 1)
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(sc.qray[b].reserve((size_t)n_items * 6));
+            HIP_TRY(sc.qitem[b].reserve(n_items));
+            HIP_TRY(sc.qpixel[b].reserve(n_items));
+        }
+    HIP_TRY(hipMemsetAsync(sc.counts.p, 0, ((size_t)n_levels + 1) * sizeof(uint32_t), stream));
+    if (counters_dev)
+        HIP_TRY(hipMemsetAsync(counters_dev, 0, sizeof(rt_counters), stream));
+
+    rt::LevelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.sv = bvh->view();
+    a.flags = flags;
+    a.depth = n_levels - 1;
+    a.parallelogram_n = p.parallelogram_n, a.segment_n = p.segment_n, a.seed = p.seed;
+    a.cam = cam;
+    a.state = sc.state.p;
+    a.n_items = n_items;
+    a.counters = counters_dev;
+    for (int32_t level = 0; level < n_levels; level++) {
+        a.level = level;
+        a.direct = sc.direct.p + (size_t)level * n_items * 3;
+        if (level == 0) {
+            a.source = source;
+            a.in = user_rays;
+            a.in_count = nullptr;
+            a.in_count_imm = n_items;
+        } else {
+            const int b = (level - 1) & 1;
+            a.source = rt::SRC_QUEUE;
+            a.in = rt::RaySoA { sc.qray[b].p, nullptr, sc.qitem[b].p, sc.qpixel[b].p, n_items };
+            a.in_count = sc.counts.p + level;
+        }
+        const int ob = level & 1;
+        a.out = rt::RaySoA { sc.qray[ob].p, nullptr, sc.qitem[ob].p, sc.qpixel[ob].p, n_items };
+        a.out_count = sc.counts.p + level + 1;
+        rt::launch_trace_level(a, counters_dev != nullptr, stream);
+    }
+    fold.direct = sc.direct.p;
+    fold.state = sc.state.p;
+    fold.n_items = n_items;
+    fold.level_stride = (size_t)n_items * 3;
+    rt::launch_fold(fold, stream);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// AoS rt_ray[] → SoA upload
+int upload_rays(Scratch& sc, const rt_ray* rays, uint32_t n, const uint32_t* pixel_ids, hipStream_t stream,
+    rt::RaySoA& out)
+{
+    std::vector<float> soa((size_t)n * 6), tt(n);
+    for (uint32_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) {
+            soa[(size_t)k * n + i] = rays[i].origin[k];
+            soa[(size_t)(3 + k) * n + i] = rays[i].direction[k];
+        }
+        tt[i] = rays[i].t;
+    }
+    HIP_TRY(sc.in_ray.reserve((size_t)n * 6));
+    HIP_TRY(sc.in_t.reserve(n));
+    HIP_TRY(hipMemcpyAsync(sc.in_ray.p, soa.data(), soa.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(sc.in_t.p, tt.data(), tt.size() * 4, hipMemcpyHostToDevice, stream));
+    out = rt::RaySoA { sc.in_ray.p, sc.in_t.p, nullptr, nullptr, n };
+    if (pixel_ids) {
+        HIP_TRY(sc.in_pixel.reserve(n));
+        HIP_TRY(hipMemcpyAsync(sc.in_pixel.p, pixel_ids, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        out.pixel = sc.in_pixel.p;
+    }
+    HIP_TRY(hipStreamSynchronize(stream)); // the staging vectors die at return
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len)
+{
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_count)
+        *device_count = n;
+    if (n == 0)
+        return fail(RT_ERR_DEVICE, "no HIP device");
+    if (name_buf && name_buf_len) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        snprintf(name_buf, name_buf_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    return RT_OK;
+}
+
+int rt_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** out)
+{
+    if (!desc || !out)
+        return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
+    std::unique_ptr<rt_scene> s(new rt_scene);
+    const std::string err = s->host.load(*desc);
+    if (!err.empty())
+        return fail(RT_ERR_INVALID, "rt_scene_create: " + err);
+    HIP_TRY(hipGetDevice(&s->device));
+    HIP_TRY(s->vnormal.upload(s->host.normals));
+    HIP_TRY(s->vtexcoord.upload(s->host.texcoords));
+    HIP_TRY(s->texels.upload(s->host.texels));
+    HIP_TRY(s->tri_vidx.upload(s->host.tri_vidx));
+    HIP_TRY(s->materials.upload(s->host.materials));
+    HIP_TRY(s->textures.upload(s->host.textures));
+    HIP_TRY(s->lights.upload(s->host.lights));
+    s->n_lights = (uint32_t)s->host.lights.size();
+    *out = s.release();
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* scene)
+{
+    delete scene;
+    return RT_OK;
+}
+
+int rt_scene_update_lights(rt_scene* scene, const rt_light_desc* lights, uint32_t n_lights)
+{
+    if (!scene || (n_lights && !lights))
+        return fail(RT_ERR_INVALID, "rt_scene_update_lights: null argument");
+    std::vector<rt::LightRec> recs;
+    const std::string err = rt::HostScene::convert_lights(lights, n_lights, recs);
+    if (!err.empty())
+        return fail(RT_ERR_INVALID, "rt_scene_update_lights: " + err);
+    std::lock_guard<std::mutex> g(scene->mu);
+    HIP_TRY(hipDeviceSynchronize()); // frames in flight still read the old lights
+    if (recs.size() > scene->lights.n) {
+        HIP_TRY(scene->lights.upload(recs));
+    } else if (!recs.empty()) {
+        HIP_TRY(hipMemcpy(scene->lights.p, recs.data(), recs.size() * sizeof(rt::LightRec), hipMemcpyHostToDevice));
+    }
+    scene->host.lights = recs;
+    scene->n_lights = n_lights;
+    return RT_OK;
+}
+
+int rt_bvh_build(rt_scene* scene, const rt_features* features, rt_bvh** out)
+{
+    if (!scene || !features || !out)
+        return fail(RT_ERR_INVALID, "rt_bvh_build: null argument");
+    std::unique_ptr<rt_bvh> b(new rt_bvh);
+    b->scene = scene;
+    const std::string err = b->host.build(scene->host, features->enableBvhSahBinning != 0);
+    if (!err.empty())
+        return fail(RT_ERR_INVALID, "rt_bvh_build: " + err);
+    HIP_TRY(b->nodes.upload(b->host.pairs));
+    HIP_TRY(b->prims.upload(b->host.records));
+    *out = b.release();
+    return RT_OK;
+}
+
+int rt_bvh_destroy(rt_bvh* bvh)
+{
+    if (bvh)
+        (void)hipDeviceSynchronize();
+    delete bvh;
+    return RT_OK;
+}
+
+int rt_bvh_num_levels(const rt_bvh* bvh) { return bvh ? bvh->host.num_levels : 0; }
+int rt_bvh_num_leaves(const rt_bvh* bvh) { return bvh ? bvh->host.num_leaves : 0; }
+int rt_bvh_num_nodes(const rt_bvh* bvh) { return bvh ? (int)bvh->host.nodes.size() : 0; }
+int rt_bvh_num_prims(const rt_bvh* bvh) { return bvh ? (int)bvh->host.prim_order.size() : 0; }
+
+int rt_bvh_export(const rt_bvh* bvh, float* node_aabb, int32_t* node_meta, int32_t* prim_order)
+{
+    if (!bvh)
+        return fail(RT_ERR_INVALID, "rt_bvh_export: null bvh");
+    for (size_t i = 0; i < bvh->host.nodes.size(); i++) {
+        const rt::RefNode& n = bvh->host.nodes[i];
+        if (node_aabb) {
+            memcpy(node_aabb + 6 * i, n.lo, 12);
+            memcpy(node_aabb + 6 * i + 3, n.hi, 12);
+        }
+        if (node_meta) {
+            int32_t* m = node_meta + 6 * i;
+            m[0] = n.leaf, m[1] = n.depth, m[2] = n.beg, m[3] = n.end, m[4] = n.left, m[5] = n.right;
+        }
+    }
+    if (prim_order)
+        memcpy(prim_order, bvh->host.prim_order.data(), bvh->host.prim_order.size() * sizeof(int32_t));
+    return RT_OK;
+}
+
+int rt_camera_from_trackball(float fovy, float aspect, const float look_at[3], float distance,
+    const float rot[3], rt_camera* out)
+{
+    if (!look_at || !rot || !out)
+        return fail(RT_ERR_INVALID, "rt_camera_from_trackball: null argument");
+    // Trackball ctor (trackball.cpp:26-27)
+    out->half_h = std::tan(fovy / 2.0f);
+    out->half_w = aspect * out->half_h;
+    // glm::quat(vec3 eulerAngle), type_quat.inl:208-217
+    const float cx = std::cos(rot[0] * 0.5f), cy = std::cos(rot[1] * 0.5f), cz = std::cos(rot[2] * 0.5f);
+    const float sx = std::sin(rot[0] * 0.5f), sy = std::sin(rot[1] * 0.5f), sz = std::sin(rot[2] * 0.5f);
+    const float w = cx * cy * cz + sx * sy * sz;
+    const float x = sx * cy * cz - cx * sy * sz;
+    const float y = cx * sy * cz + sx * cy * sz;
+    const float z = cx * cy * sz - sx * sy * cz;
+    out->quat[0] = w, out->quat[1] = x, out->quat[2] = y, out->quat[3] = z;
+    // position() = lookAt + quat * vec3(0, 0, -dist) (trackball.cpp:71-74); quat*vec: type_quat.inl:347-354
+    const float v[3] = { 0.0f, 0.0f, -distance };
+    const float uv[3] = { y * v[2] - v[1] * z, z * v[0] - v[2] * x, x * v[1] - v[0] * y };
+    const float uuv[3] = { y * uv[2] - uv[1] * z, z * uv[0] - uv[2] * x, x * uv[1] - uv[0] * y };
+    for (int k = 0; k < 3; k++)
+        out->origin[k] = look_at[k] + (v[k] + ((uv[k] * w) + uuv[k]) * 2.0f);
+    return RT_OK;
+}
+
+int rt_render_device(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features,
+    const rt_render_params* params, int32_t width, int32_t height, const int32_t* rows, int32_t n_rows,
+    int32_t packed, float* rgb_dev, rt_counters* counters_dev, void* hip_stream)
+{
+    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
+    if (!bvh || !camera || !rgb_dev)
+        return fail(RT_ERR_INVALID, "rt_render_device: null argument");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30)
+        return fail(RT_ERR_INVALID, "rt_render_device: bad resolution");
+    int rc = check_features(features, bvh);
+    if (rc == RT_OK)
+        rc = check_params(params);
+    if (rc != RT_OK)
+        return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Scratch& sc = bvh->scratch_for(hip_stream);
+    rt::CameraArgs cam = camera_args(*camera, width, height);
+    if (rows) {
+        if (n_rows < 0)
+            return fail(RT_ERR_INVALID, "rt_render_device: n_rows < 0");
+        for (int32_t i = 0; i < n_rows; i++)
+            if (rows[i] < 0 || rows[i] >= height)
+                return fail(RT_ERR_INVALID, "rt_render_device: row out of range");
+        if (sc.rows_host.size() != (size_t)n_rows || memcmp(sc.rows_host.data(), rows, (size_t)n_rows * 4) != 0) {
+            sc.rows_host.assign(rows, rows + n_rows);
+            HIP_TRY(sc.rows.reserve((size_t)n_rows));
+            if (n_rows)
+                HIP_TRY(hipMemcpyAsync(sc.rows.p, sc.rows_host.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice,
+                    stream));
+        }
+        cam.rows = sc.rows.p;
+        cam.n_rows = n_rows;
+    }
+    if (cam.n_rows == 0)
+        return RT_OK;
+    rt::FoldArgs fold;
+    memset(&fold, 0, sizeof(fold));
+    fold.width = width, fold.height = height, fold.row0 = cam.row0, fold.packed = packed, fold.rows = cam.rows;
+    fold.out = rgb_dev;
+    const uint32_t n_items = (uint32_t)cam.n_rows * (uint32_t)width;
+    return enqueue_trace(bvh, sc, *features, *params, rt::SRC_CAMERA, cam, rt::RaySoA {}, n_items, fold,
+        counters_dev, stream);
+}
+
+int rt_render(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features,
+    const rt_render_params* params, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, float* rgb,
+    rt_counters* counters)
+{
+    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
+    if (!bvh || !camera || !rgb)
+        return fail(RT_ERR_INVALID, "rt_render: null argument");
+    if (width <= 0 || height <= 0 || row_begin < 0 || row_end > height || row_begin > row_end)
+        return fail(RT_ERR_INVALID, "rt_render: bad resolution / row range");
+    if (row_begin == row_end)
+        return RT_OK;
+    int rc = check_features(features, bvh);
+    if (rc == RT_OK)
+        rc = check_params(params);
+    if (rc != RT_OK)
+        return rc;
+    std::lock_guard<std::mutex> g(g_host_call_mu);
+    Scratch& sc = bvh->scratch_for(nullptr);
+    const size_t frame_floats = (size_t)width * height * 3;
+    HIP_TRY(sc.frame.reserve(frame_floats));
+    if (counters)
+        HIP_TRY(sc.counters.reserve(1));
+    rt::CameraArgs cam = camera_args(*camera, width, height);
+    cam.row0 = row_begin, cam.n_rows = row_end - row_begin;
+    rt::FoldArgs fold;
+    memset(&fold, 0, sizeof(fold));
+    fold.width = width, fold.height = height, fold.row0 = row_begin, fold.packed = 0, fold.rows = nullptr;
+    fold.out = sc.frame.p;
+    const uint32_t n_items = (uint32_t)cam.n_rows * (uint32_t)width;
+    rc = enqueue_trace(bvh, sc, *features, *params, rt::SRC_CAMERA, cam, rt::RaySoA {}, n_items, fold,
+        counters ? sc.counters.p : nullptr, nullptr);
+    if (rc != RT_OK)
+        return rc;
+    // rows [row_begin,row_end) occupy flipped rows [H-row_end, H-row_begin)
+    const size_t off = (size_t)(height - row_end) * width * 3;
+    HIP_TRY(hipMemcpy(rgb + off, sc.frame.p + off, (size_t)cam.n_rows * width * 3 * sizeof(float),
+        hipMemcpyDeviceToHost));
+    if (counters)
+        HIP_TRY(hipMemcpy(counters, sc.counters.p, sizeof(rt_counters), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_render_hits(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features, int32_t width,
+    int32_t height, uint32_t* t_bits, int32_t* prim)
+{
+    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
+    if (!bvh || !camera || !features)
+        return fail(RT_ERR_INVALID, "rt_render_hits: null argument");
+    if (width <= 0 || height <= 0)
+        return fail(RT_ERR_INVALID, "rt_render_hits: bad resolution");
+    std::lock_guard<std::mutex> g(g_host_call_mu);
+    Scratch& sc = bvh->scratch_for(nullptr);
+    const size_t n = (size_t)width * height;
+    HIP_TRY(sc.t_bits.reserve(n));
+    HIP_TRY(sc.prim.reserve(n));
+    rt::IntersectArgs a;
+    memset(&a, 0, sizeof(a));
+    a.sv = bvh->view();
+    a.flags = feature_flags(*features);
+    a.source = rt::SRC_CAMERA;
+    a.cam = camera_args(*camera, width, height);
+    a.t_bits = sc.t_bits.p;
+    a.prim = sc.prim.p;
+    rt::launch_intersect(a, false, nullptr);
+    HIP_TRY(hipGetLastError());
+    if (t_bits)
+        HIP_TRY(hipMemcpy(t_bits, sc.t_bits.p, n * 4, hipMemcpyDeviceToHost));
+    if (prim)
+        HIP_TRY(hipMemcpy(prim, sc.prim.p, n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_trace_batch(const rt_bvh* cbvh, const rt_ray* rays, uint32_t n_rays, const uint32_t* pixel_ids,
+    const rt_features* features, const rt_render_params* params, float* rgb, rt_counters* counters)
+{
+    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
+    if (!bvh || (n_rays && (!rays || !rgb)))
+        return fail(RT_ERR_INVALID, "rt_trace_batch: null argument");
+    int rc = check_features(features, bvh);
+    if (rc == RT_OK)
+        rc = check_params(params);
+    if (rc != RT_OK || n_rays == 0)
+        return rc;
+    std::lock_guard<std::mutex> g(g_host_call_mu);
+    Scratch& sc = bvh->scratch_for(nullptr);
+    rt::RaySoA in;
+    rc = upload_rays(sc, rays, n_rays, pixel_ids, nullptr, in);
+    if (rc != RT_OK)
+        return rc;
+    HIP_TRY(sc.frame.reserve((size_t)n_rays * 3));
+    if (counters)
+        HIP_TRY(sc.counters.reserve(1));
+    rt::FoldArgs fold;
+    memset(&fold, 0, sizeof(fold));
+    fold.out = sc.frame.p; // width == 0 → out[item]
+    rt::CameraArgs cam;
+    memset(&cam, 0, sizeof(cam));
+    rc = enqueue_trace(bvh, sc, *features, *params, rt::SRC_RAYS, cam, in, n_rays, fold,
+        counters ? sc.counters.p : nullptr, nullptr);
+    if (rc != RT_OK)
+        return rc;
+    HIP_TRY(hipMemcpy(rgb, sc.frame.p, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (counters)
+        HIP_TRY(hipMemcpy(counters, sc.counters.p, sizeof(rt_counters), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_intersect_batch(const rt_bvh* cbvh, rt_ray* rays, uint32_t n_rays, const rt_features* features, rt_hit* hits,
+    rt_counters* counters)
+{
+    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
+    if (!bvh || !features || (n_rays && !rays))
+        return fail(RT_ERR_INVALID, "rt_intersect_batch: null argument");
+    if (n_rays == 0)
+        return RT_OK;
+    std::lock_guard<std::mutex> g(g_host_call_mu);
+    Scratch& sc = bvh->scratch_for(nullptr);
+    rt::RaySoA in;
+    int rc = upload_rays(sc, rays, n_rays, nullptr, nullptr, in);
+    if (rc != RT_OK)
+        return rc;
+    HIP_TRY(sc.hits.reserve(n_rays));
+    HIP_TRY(sc.frame.reserve(n_rays));
+    if (counters) {
+        HIP_TRY(sc.counters.reserve(1));
+        HIP_TRY(hipMemset(sc.counters.p, 0, sizeof(rt_counters)));
+    }
+    rt::IntersectArgs a;
+    memset(&a, 0, sizeof(a));
+    a.sv = bvh->view();
+    a.flags = feature_flags(*features);
+    a.source = rt::SRC_RAYS;
+    a.in = in;
+    a.n_rays = n_rays;
+    a.hits = sc.hits.p;
+    a.t_out = sc.frame.p;
+    a.counters = counters ? sc.counters.p : nullptr;
+    rt::launch_intersect(a, counters != nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> tt(n_rays);
+    HIP_TRY(hipMemcpy(tt.data(), sc.frame.p, (size_t)n_rays * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_rays; i++)
+        rays[i].t = tt[i];
+    if (hits)
+        HIP_TRY(hipMemcpy(hits, sc.hits.p, (size_t)n_rays * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    if (counters)
+        HIP_TRY(hipMemcpy(counters, sc.counters.p, sizeof(rt_counters), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_deinterleave_strips(const float* gathered_dev, float* frame_dev, int32_t width, int32_t height,
+    int32_t strip_rows, int32_t n_ranks, void* hip_stream)
+{
+    if (!gathered_dev || !frame_dev || width <= 0 || height <= 0 || strip_rows <= 0 || n_ranks <= 0)
+        return fail(RT_ERR_INVALID, "rt_deinterleave_strips: bad argument");
+    rt::launch_deinterleave(gathered_dev, frame_dev, width, height, strip_rows, n_ranks, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+uint32_t rt_rand31(uint32_t seed, uint32_t pixel, uint32_t level, uint32_t light, uint32_t sample, uint32_t dim)
+{
+    auto pcg = [](uint32_t v) {
+        const uint32_t state = v * 747796405u + 2891336453u;
+        const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+        return (word >> 22u) ^ word;
+    };
+    uint32_t h = pcg(seed ^ 0x9E3779B9u);
+    h = pcg(h + pixel);
+    h = pcg(h ^ ((level << 26) | (light << 18) | (sample << 1) | dim));
+    return h & 0x7fffffffu;
+}
+
+} // extern "C"

@@ -1,0 +1,83 @@
+// rt_kernels.h — launch interface between the C ABI (rt_capi.hip) and the HIP
+// kernels (rt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/rt_whitted.h"
+#include "rt_layout.h"
+
+namespace rt {
+
+enum : int32_t { SRC_CAMERA = 0, SRC_QUEUE = 1, SRC_RAYS = 2 };
+
+// Ray queue / user ray batch in SoA form: 6 float arrays of `cap` entries
+// (ox, oy, oz, dx, dy, dz) at ray[k*cap + i], optional t, item and pixel ids.
+struct RaySoA {
+    float* ray;
+    float* t;        // NULL → FLT_MAX
+    uint32_t* item;  // NULL → i
+    uint32_t* pixel; // NULL → i
+    uint32_t cap;
+};
+
+struct CameraArgs {
+    float origin[3], quat[4], half_w, half_h;
+    int32_t width, height;
+    const int32_t* rows; // device list of image rows, NULL → row0 + local row
+    int32_t row0, n_rows;
+};
+
+// One recursion level of the flattened Whitted recursion (k_trace_level).
+struct LevelArgs {
+    SceneView sv;
+    uint32_t flags;
+    int32_t level, depth;
+    int32_t parallelogram_n, segment_n;
+    uint32_t seed;
+    int32_t source;
+    CameraArgs cam;
+    RaySoA in;
+    const uint32_t* in_count; // device count for SRC_QUEUE
+    uint32_t in_count_imm;    // count for SRC_RAYS
+    RaySoA out;
+    uint32_t* out_count;
+    float* direct;   // this level's direct-light colours, n_items * 3
+    uint32_t* state; // per item: bits 0..7 = levels that hit, bit 8 = chain ended on a miss
+    uint32_t n_items;
+    rt_counters* counters; // NULL unless counting build
+};
+
+struct FoldArgs {
+    const float* direct; // (depth + 1) level slices of n_items * 3
+    const uint32_t* state;
+    uint32_t n_items;
+    size_t level_stride; // floats between level slices
+    // output mapping: batch (width == 0): out[item]; frame: item = local_row*W + x →
+    // packed: same index; flipped: (H-1-y)*W + x with y = rows ? rows[local_row] : row0 + local_row
+    int32_t width, height, row0, packed;
+    const int32_t* rows;
+    float* out;
+};
+
+struct IntersectArgs {
+    SceneView sv;
+    uint32_t flags;
+    int32_t source; // SRC_CAMERA (primary rays of a frame) or SRC_RAYS
+    CameraArgs cam;
+    RaySoA in;
+    uint32_t n_rays;
+    // outputs (any may be NULL); for SRC_CAMERA indices are row-flipped frame positions
+    uint32_t* t_bits;
+    int32_t* prim;
+    rt_hit* hits;
+    float* t_out; // updated ray.t per ray (SRC_RAYS)
+    rt_counters* counters;
+};
+
+void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s);
+void launch_fold(const FoldArgs& a, hipStream_t s);
+void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s);
+void launch_deinterleave(const float* gathered, float* frame, int32_t width, int32_t height, int32_t strip_rows,
+    int32_t n_ranks, hipStream_t s);
+
+} // namespace rt

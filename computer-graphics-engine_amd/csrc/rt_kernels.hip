@@ -1,0 +1,448 @@
+// rt_kernels.hip — HIP kernels of the Whitted render path for gfx950 (MI355X).
+//
+//   k_trace_level  one level of the flattened recursion of recursiveRayTrace
+//                  (src/render.cpp:27-150): ray fetch (camera tile at level 0 —
+//                  render.cpp:286-289,317 + trackball.cpp:101-110 — or the
+//                  compacted reflection queue), closest-hit packet traversal
+//                  (bvh.cpp:299-362), hit attributes (bvh.cpp:365-426), the light
+//                  loop with shadow packets (light.cpp:49-73,108-165), Phong
+//                  (shading.cpp:7-37), reflection spawn (shading.cpp:40-62) with
+//                  wave-ballot compaction into the next level's queue.
+//   k_fold         back-to-front colour fold `Lo = (direct + r) + r`
+//                  (render.cpp:100,118) and the framebuffer write
+//                  (render.cpp:322-323 → screen.cpp:41-47).
+//   k_intersect    ≙ BvhInterface::intersect on a batch / the primary rays.
+//   k_deinterleave multi-GPU strip gather → row-flipped frame.
+//
+// Each reflection ray is traversed ONCE: the reference traces the same ray
+// twice (render.cpp:100 and :118) and adds the two identical results one after
+// the other, which the fold reproduces as (direct + r) + r.
+#include "rt_kernels.h"
+#include "rt_shade.h"
+
+namespace rt {
+
+namespace {
+
+constexpr int kBlock = 256; // 4 waves, one 8x8 pixel tile (or 64 queued rays) each
+
+RT_DEV V3 quat_rotate(const float* q, V3 v)
+{
+    // glm/detail/type_quat.inl:347-354: v + ((uv * q.w) + uuv) * 2
+    const V3 qv = mk(q[1], q[2], q[3]);
+    const V3 uv = cross(qv, v);
+    const V3 uuv = cross(qv, uv);
+    return v + ((uv * q[0]) + uuv) * 2.0f;
+}
+
+// Trackball::generateRay (trackball.cpp:101-110) for pixel (x, y) of a W x H frame
+RT_DEV RayL camera_ray(const CameraArgs& c, int32_t x, int32_t y)
+{
+    const float px = float(x) / float(c.width) * 2.0f - 1.0f; // render.cpp:286-289
+    const float py = float(y) / float(c.height) * 2.0f - 1.0f;
+    const V3 csd = normalize(mk(-px * c.half_w, py * c.half_h, 1.0f));
+    RayL r;
+    r.o = mk(c.origin[0], c.origin[1], c.origin[2]);
+    r.d = quat_rotate(c.quat, csd);
+    return r;
+}
+
+// lane → pixel of an 8x8 tile; returns false for lanes outside the frame / row list
+RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_t& x, int32_t& y, int32_t& lrow)
+{
+    const uint32_t tiles_x = (uint32_t)(c.width + 7) >> 3;
+    const uint32_t ty = wave / tiles_x, tx = wave - ty * tiles_x;
+    x = (int32_t)(tx * 8u + (lane & 7u));
+    lrow = (int32_t)(ty * 8u + (lane >> 3));
+    const bool ok = x < c.width && lrow < c.n_rows;
+    y = 0;
+    if (ok)
+        y = c.rows ? c.rows[lrow] : c.row0 + lrow;
+    return ok;
+}
+
+RT_DEV uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct RayCounts {
+    uint32_t closest = 0, shadow = 0, hits = 0, queued = 0;
+};
+
+RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCounts& rc, int32_t level, uint32_t lane)
+{
+    const uint32_t box = wave_sum(lc.box), tri = wave_sum(lc.tri), sph = wave_sum(lc.sph);
+    const uint32_t closest = wave_sum(rc.closest), shadow = wave_sum(rc.shadow);
+    const uint32_t hits = wave_sum(rc.hits), queued = wave_sum(rc.queued);
+    if (lane == 0) {
+        auto add = [](uint64_t* p, uint64_t v) {
+            if (v)
+                atomicAdd((unsigned long long*)p, (unsigned long long)v);
+        };
+        add(&out->rays, (uint64_t)closest + shadow);
+        add(level == 0 ? &out->rays_primary : &out->rays_reflect, closest);
+        add(&out->rays_shadow, shadow);
+        add(&out->rays_ref_equiv, ((uint64_t)closest + shadow) << (level > 0 ? level : 0));
+        add(&out->box_tests, box);
+        add(&out->tri_tests, tri);
+        add(&out->sphere_tests, sph);
+        add(&out->node_fetches, lc.node_fetch);
+        add(&out->tri_fetches, lc.tri_fetch);
+        add(&out->hits_shaded, hits);
+        add(&out->rays_queued, queued);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_level(const LevelArgs a)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uni(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    const SceneView& sv = a.sv;
+    const uint32_t flags = a.flags;
+    const bool use_bvh = (flags & F_ACCEL) != 0;
+
+    // ---- fetch this lane's ray ------------------------------------------------
+    bool active = false;
+    RayL ray;
+    ray.o = mk(0, 0, 0), ray.d = mk(0, 0, -1);
+    float t = kFltMax;
+    uint32_t item = 0, pixel = 0;
+    if (a.source == SRC_CAMERA) {
+        int32_t x, y, lrow;
+        active = tile_pixel(a.cam, wave, lane, x, y, lrow);
+        if (active) {
+            ray = camera_ray(a.cam, x, y);
+            item = (uint32_t)lrow * (uint32_t)a.cam.width + (uint32_t)x;
+            pixel = (uint32_t)y * (uint32_t)a.cam.width + (uint32_t)x;
+        }
+    } else {
+        const uint32_t count = a.source == SRC_QUEUE ? *a.in_count : a.in_count_imm;
+        const uint32_t i = wave * 64u + lane;
+        active = i < count;
+        if (active) {
+            const float* q = a.in.ray;
+            const size_t cap = a.in.cap;
+            ray.o = mk(q[i], q[cap + i], q[2 * cap + i]);
+            ray.d = mk(q[3 * cap + i], q[4 * cap + i], q[5 * cap + i]);
+            if (a.in.t)
+                t = a.in.t[i];
+            item = a.in.item ? a.in.item[i] : i;
+            pixel = a.in.pixel ? a.in.pixel[i] : i;
+        }
+    }
+    if (ballot(active) == 0)
+        return;
+
+    LaneCounters lc;
+    RayCounts rc;
+    if (COUNT && active)
+        rc.closest = 1;
+
+    // ---- closest hit (bvh.intersect, render.cpp:31) -----------------------------
+    int32_t pos;
+    traverse<false, COUNT>(sv, use_bvh, active, ray, t, pos, lc);
+    const bool hit = active && pos >= 0;
+    if (active) {
+        if (hit)
+            a.state[item] = (uint32_t)a.level + 1u;
+        else if (a.level == 0)
+            a.state[item] = 0u;
+        else
+            a.state[item] |= 0x100u; // the reflected ray left the scene: Lo += vec3(0) twice
+    }
+
+    HitL h;
+    h.normal = mk(0, 0, 1), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
+    h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
+    if (hit)
+        resolve_hit(sv, flags, ray, t, pos, h);
+    if (COUNT && hit)
+        rc.hits = 1;
+
+    // ---- computeLightContribution (light.cpp:108-165) ---------------------------
+    V3 Lo = h.kd; // !enableShading: the albedo (light.cpp:161-164)
+    if (flags & F_SHADING) {
+        V3 result = mk(0.0f, 0.0f, 0.0f);
+        const LightRec RT_CONST_AS* lights = (const LightRec RT_CONST_AS*)sv.lights;
+        for (uint32_t li = 0; li < sv.n_lights; li++) {
+            const LightRec RT_CONST_AS* L = lights + li;
+            const int32_t kind = L->kind;
+            const bool is_point = kind == RT_LIGHT_POINT;
+            if (!is_point && !(flags & F_SOFT_SHADOW))
+                continue; // segment / parallelogram lights only contribute with soft shadows
+            const bool trace_shadow = is_point ? (flags & F_HARD_SHADOW) != 0 : true;
+            const int32_t n = a.parallelogram_n;
+            const int32_t nsamp = is_point ? 1 : (kind == RT_LIGHT_SEGMENT ? a.segment_n : n * n);
+            V3 acc = mk(0.0f, 0.0f, 0.0f);
+            for (int32_t s = 0; s < nsamp; s++) {
+                V3 lpos, lcol;
+                if (is_point) {
+                    lpos = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
+                    lcol = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
+                } else if (kind == RT_LIGHT_SEGMENT) { // sampleSegmentLight, light.cpp:19-26
+                    const V3 e0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]), e1 = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
+                    const V3 c0 = mk(L->v[2][0], L->v[2][1], L->v[2][2]), c1 = mk(L->v[3][0], L->v[3][1], L->v[3][2]);
+                    const float r = rand01(rand31(a.seed, pixel, (uint32_t)a.level, li, (uint32_t)s, 0u));
+                    const float weight = ((float)s + r) / (float)a.segment_n;
+                    lpos = (e1 - e0) * weight + e0;
+                    lcol = weight * c1 + (1 - weight) * c0;
+                } else { // sampleParallelogramLight, light.cpp:30-45
+                    const int32_t i = s / n, k = s - i * n;
+                    const V3 v0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
+                    const V3 e01 = mk(L->v[1][0], L->v[1][1], L->v[1][2]), e02 = mk(L->v[2][0], L->v[2][1], L->v[2][2]);
+                    const V3 c0 = mk(L->v[3][0], L->v[3][1], L->v[3][2]), c1 = mk(L->v[4][0], L->v[4][1], L->v[4][2]);
+                    const V3 c2 = mk(L->v[5][0], L->v[5][1], L->v[5][2]), c3 = mk(L->v[6][0], L->v[6][1], L->v[6][2]);
+                    const float horRandom = rand01(rand31(a.seed, pixel, (uint32_t)a.level, li, (uint32_t)s, 0u));
+                    const float verRandom = rand01(rand31(a.seed, pixel, (uint32_t)a.level, li, (uint32_t)s, 1u));
+                    const float horWeight = ((float)i + horRandom) / (float)n;
+                    const float verWeight = ((float)k + verRandom) / (float)n;
+                    const V3 horVector = horWeight * e01;
+                    const V3 verVector = verWeight * e02;
+                    lpos = v0 + horVector + verVector;
+                    const V3 bottomColor = horWeight * c1 + (1 - horWeight) * c0;
+                    const V3 topColor = horWeight * c3 + (1 - horWeight) * c2;
+                    lcol = verWeight * topColor + (1 - verWeight) * bottomColor;
+                }
+                float visibility = 1.0f;
+                if (trace_shadow) { // testVisibilityLightSample, light.cpp:49-73
+                    const RayL sray = shadow_ray(ray, t, lpos);
+                    float st = 1.0f;
+                    int32_t spos;
+                    if (COUNT && hit)
+                        rc.shadow++;
+                    traverse<true, COUNT>(sv, use_bvh, hit, sray, st, spos, lc);
+                    if (spos >= 0)
+                        visibility = 0.0f;
+                }
+                V3 color = mk(0.0f, 0.0f, 0.0f);
+                if (hit)
+                    color = compute_shading(lpos, lcol, ray, t, h);
+                if (is_point)
+                    result = result + color * visibility;
+                else
+                    acc = acc + color * visibility;
+            }
+            if (!is_point) {
+                const float denom = kind == RT_LIGHT_SEGMENT ? (float)a.segment_n : (float)n * (float)n;
+                result = result + acc / denom;
+            }
+        }
+        Lo = result;
+    }
+    if (hit) {
+        float* d = a.direct + 3 * (size_t)item;
+        d[0] = Lo.x, d[1] = Lo.y, d[2] = Lo.z;
+    }
+
+    // ---- reflection spawn (render.cpp:34,52-54,100,113-119) ---------------------
+    bool spawn = false;
+    RayL refl;
+    refl.o = mk(0, 0, 0), refl.d = mk(0, 0, 0);
+    if (hit && (flags & F_RECURSIVE) && a.level < a.depth)
+        spawn = compute_reflection_ray(ray, t, h, refl);
+    const uint64_t smask = ballot(spawn);
+    if (COUNT && spawn)
+        rc.queued = 1;
+    if (smask) {
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(a.out_count, (uint32_t)__builtin_popcountll(smask));
+        base = uni(base);
+        if (spawn) {
+            const uint32_t o = base + prefix_count(smask);
+            if (o < a.out.cap) {
+                float* q = a.out.ray;
+                const size_t cap = a.out.cap;
+                q[o] = refl.o.x, q[cap + o] = refl.o.y, q[2 * cap + o] = refl.o.z;
+                q[3 * cap + o] = refl.d.x, q[4 * cap + o] = refl.d.y, q[5 * cap + o] = refl.d.z;
+                a.out.item[o] = item;
+                a.out.pixel[o] = pixel;
+            }
+        }
+    }
+    if (COUNT)
+        flush_counters(a.counters, lc, rc, a.level, lane);
+}
+
+__global__ __launch_bounds__(256) void k_fold(const FoldArgs a)
+{
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    if (item >= a.n_items)
+        return;
+    const uint32_t s = a.state[item];
+    const int32_t n = (int32_t)(s & 0xffu);
+    V3 c = mk(0.0f, 0.0f, 0.0f);
+    if (n > 0) {
+        c = ld3(a.direct + (size_t)(n - 1) * a.level_stride + 3 * (size_t)item);
+        if (s & 0x100u) { // deepest reflection missed: Lo += vec3(0), twice (render.cpp:100,118,148)
+            c = c + mk(0.0f, 0.0f, 0.0f);
+            c = c + mk(0.0f, 0.0f, 0.0f);
+        }
+        for (int32_t j = n - 2; j >= 0; j--) {
+            const V3 d = ld3(a.direct + (size_t)j * a.level_stride + 3 * (size_t)item);
+            c = (d + c) + c;
+        }
+    }
+    // render.cpp:283,318,322: colorSum = vec3(0) + colour; finalColor = colorSum / float(1)
+    V3 colorSum = mk(0.0f, 0.0f, 0.0f) + c;
+    const V3 finalColor = colorSum / 1.0f;
+    size_t o = item;
+    if (a.width > 0 && !a.packed) {
+        const int32_t lrow = (int32_t)(item / (uint32_t)a.width);
+        const int32_t x = (int32_t)(item - (uint32_t)lrow * (uint32_t)a.width);
+        const int32_t y = a.rows ? a.rows[lrow] : a.row0 + lrow;
+        o = (size_t)(a.height - 1 - y) * a.width + x; // Screen::setPixel, screen.cpp:45
+    }
+    float* p = a.out + 3 * o;
+    p[0] = finalColor.x, p[1] = finalColor.y, p[2] = finalColor.z;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect(const IntersectArgs a)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uni(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    bool active = false;
+    RayL ray;
+    ray.o = mk(0, 0, 0), ray.d = mk(0, 0, -1);
+    float t = kFltMax;
+    size_t out_idx = 0;
+    if (a.source == SRC_CAMERA) {
+        int32_t x, y, lrow;
+        active = tile_pixel(a.cam, wave, lane, x, y, lrow);
+        if (active) {
+            ray = camera_ray(a.cam, x, y);
+            out_idx = (size_t)(a.cam.height - 1 - y) * a.cam.width + x;
+        }
+    } else {
+        const uint32_t i = wave * 64u + lane;
+        active = i < a.n_rays;
+        if (active) {
+            const float* q = a.in.ray;
+            const size_t cap = a.in.cap;
+            ray.o = mk(q[i], q[cap + i], q[2 * cap + i]);
+            ray.d = mk(q[3 * cap + i], q[4 * cap + i], q[5 * cap + i]);
+            t = a.in.t[i];
+            out_idx = i;
+        }
+    }
+    if (ballot(active) == 0)
+        return;
+    LaneCounters lc;
+    RayCounts rc;
+    if (COUNT && active)
+        rc.closest = 1;
+    int32_t pos;
+    traverse<false, COUNT>(a.sv, (a.flags & F_ACCEL) != 0, active, ray, t, pos, lc);
+    if (active) {
+        const bool hit = pos >= 0;
+        HitL h;
+        h.normal = mk(0, 0, 0), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
+        h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
+        int32_t prim = -1;
+        if (hit)
+            prim = resolve_hit(a.sv, a.flags, ray, t, pos, h);
+        if (a.t_bits)
+            a.t_bits[out_idx] = __float_as_uint(t);
+        if (a.prim)
+            a.prim[out_idx] = prim;
+        if (a.t_out)
+            a.t_out[out_idx] = t;
+        if (a.hits) {
+            rt_hit o;
+            o.hit = hit ? 1 : 0;
+            o.prim = prim;
+            o.t = t;
+            o.normal[0] = h.normal.x, o.normal[1] = h.normal.y, o.normal[2] = h.normal.z;
+            o.material.kd[0] = h.kd.x, o.material.kd[1] = h.kd.y, o.material.kd[2] = h.kd.z;
+            o.material.ks[0] = h.ks.x, o.material.ks[1] = h.ks.y, o.material.ks[2] = h.ks.z;
+            o.material.shininess = h.shininess;
+            o.material.transparency = h.transparency;
+            o.material.texture = h.texture;
+            a.hits[out_idx] = o;
+        }
+    }
+    if (COUNT)
+        flush_counters(a.counters, lc, rc, 0, lane);
+}
+
+// gathered: n_ranks blocks of rows_max*W*3 floats; strip s (strip_rows image rows)
+// was rendered by rank s % n_ranks as its local strip s / n_ranks.
+__global__ __launch_bounds__(256) void k_deinterleave(const float* __restrict__ gathered, float* __restrict__ frame,
+    int32_t width, int32_t height, int32_t strip_rows, int32_t n_ranks, int32_t rows_max)
+{
+    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x; // (y, x)
+    if (idx >= (size_t)width * height)
+        return;
+    const int32_t y = (int32_t)(idx / (size_t)width);
+    const int32_t x = (int32_t)(idx - (size_t)y * width);
+    const int32_t strip = y / strip_rows;
+    const int32_t rank = strip % n_ranks;
+    const int32_t lrow = (strip / n_ranks) * strip_rows + (y - strip * strip_rows);
+    const float* src = gathered + ((size_t)rank * rows_max + lrow) * (size_t)width * 3 + 3 * (size_t)x;
+    float* dst = frame + ((size_t)(height - 1 - y) * width + x) * 3;
+    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2];
+}
+
+uint32_t grid_for_waves(uint64_t waves) { return (uint32_t)((waves + (kBlock / 64) - 1) / (kBlock / 64)); }
+
+uint64_t camera_waves(const CameraArgs& c)
+{
+    return (uint64_t)((c.width + 7) / 8) * (uint64_t)((c.n_rows + 7) / 8);
+}
+
+} // namespace
+
+void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
+{
+    uint64_t waves;
+    if (a.source == SRC_CAMERA)
+        waves = camera_waves(a.cam);
+    else if (a.source == SRC_QUEUE)
+        waves = ((uint64_t)a.in.cap + 63) / 64; // worst case; waves past *in_count exit at once
+    else
+        waves = ((uint64_t)a.in_count_imm + 63) / 64;
+    if (waves == 0)
+        return;
+    const uint32_t grid = grid_for_waves(waves);
+    if (count)
+        hipLaunchKernelGGL(k_trace_level<true>, dim3(grid), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_trace_level<false>, dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+void launch_fold(const FoldArgs& a, hipStream_t s)
+{
+    if (a.n_items == 0)
+        return;
+    hipLaunchKernelGGL(k_fold, dim3((a.n_items + 255) / 256), dim3(256), 0, s, a);
+}
+
+void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s)
+{
+    const uint64_t waves = a.source == SRC_CAMERA ? camera_waves(a.cam) : ((uint64_t)a.n_rays + 63) / 64;
+    if (waves == 0)
+        return;
+    const uint32_t grid = grid_for_waves(waves);
+    if (count)
+        hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+void launch_deinterleave(const float* gathered, float* frame, int32_t width, int32_t height, int32_t strip_rows,
+    int32_t n_ranks, hipStream_t s)
+{
+    const int32_t n_strips = (height + strip_rows - 1) / strip_rows;
+    const int32_t rows_max = ((n_strips + n_ranks - 1) / n_ranks) * strip_rows;
+    const size_t n = (size_t)width * height;
+    hipLaunchKernelGGL(k_deinterleave, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, gathered, frame, width,
+        height, strip_rows, n_ranks, rows_max);
+}
+
+} // namespace rt

@@ -1,0 +1,89 @@
+// rt_layout.h — HBM data layout shared by the host builder and the HIP kernels.
+//
+// Everything a WAVE fetches during traversal is laid out as one contiguous,
+// 32-byte-aligned record per fetch so that a wave-uniform index turns into
+// scalar (SMEM) loads: one 64-byte NodePair per internal node visited, one
+// 96-byte PrimRecord per leaf primitive tested. Per-LANE gathers (vertex
+// attributes, materials, texels) happen once per shaded hit and use plain
+// arrays.
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+// Children of one internal node (src/bounding_volume_hierarchy.cpp:331-355 reads
+// nodes[left].aabb and nodes[right].aabb of the popped parent). Child reference:
+// cnt == 0 → internal node, ref = index of ITS NodePair; cnt > 0 → leaf holding
+// permuted primitives [ref, ref + cnt).
+struct alignas(64) NodePair {
+    float l_lo[3], l_hi[3];
+    float r_lo[3], r_hi[3];
+    uint32_t l_ref, l_cnt;
+    uint32_t r_ref, r_cnt;
+};
+static_assert(sizeof(NodePair) == 64, "NodePair must be one 64-byte record");
+
+enum : uint32_t { PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u };
+
+// One primitive in BVH (permuted) order. For a triangle the per-primitive part
+// of intersectRayWithTriangle is hoisted here: it
+// depends on the vertices only, and is computed on the host with the same
+// operation order, so per-ray results stay bit-identical:
+//   n  = normalize(cross(v1 - v0, v2 - v0)),  D = dot(v0, n)
+//   e0 = cross(v2 - v0, n), e1 = cross(v0 - v1, n), e2 = cross(v1 - v2, n)
+// For a sphere: v0 = center, D = radius.
+struct alignas(32) PrimRecord {
+    float n[3];
+    float D;
+    float e0[3];
+    float e1[3];
+    float e2[3];
+    float v0[3];
+    float v1[3];
+    float v2[3];
+    int32_t prim_id;   // pre-permutation id (triangles mesh-major, then spheres)
+    uint32_t kind_mat; // bit 31: PRIM_SPHERE; bits 0..30: material slot (mesh index, or n_meshes + sphere index)
+};
+static_assert(sizeof(PrimRecord) == 96, "PrimRecord must be 96 bytes");
+
+// Material slot (framework mesh.h:22-34 without the shared_ptr)
+struct alignas(16) MaterialRec {
+    float kd[3];
+    float shininess;
+    float ks[3];
+    float transparency;
+    int32_t texture; // -1 none
+    int32_t pad[3];
+};
+static_assert(sizeof(MaterialRec) == 48, "MaterialRec");
+
+struct TextureRec {
+    uint32_t offset; // first texel (in float3 units) in the texel pool
+    int32_t width, height;
+    int32_t pad;
+};
+
+struct LightRec {
+    int32_t kind;
+    float v[7][3];
+    int32_t pad[2];
+};
+static_assert(sizeof(LightRec) == 96, "LightRec");
+
+// Device view of a built scene + BVH (all pointers into HBM).
+struct SceneView {
+    const NodePair* nodes;
+    const PrimRecord* prims;    // permuted (BVH) order
+    const uint32_t* tri_vidx;   // prim_id*3 → global vertex index (triangles only)
+    const float* vnormal;       // global vertex normals, xyz
+    const float* vtexcoord;     // global vertex texcoords, uv
+    const MaterialRec* materials;
+    const TextureRec* textures;
+    const float* texels;        // rgb pool
+    const LightRec* lights;
+    uint32_t n_lights;
+    uint32_t root_ref, root_cnt; // child reference of the root (never box-tested: bvh.cpp:313)
+    uint32_t n_prims;
+};
+
+} // namespace rt

@@ -171,6 +171,8 @@ typedef struct rt_counters {
     uint64_t sphere_tests;
     uint64_t node_fetches;   /* wave-level internal-node fetches (64 B each) */
     uint64_t tri_fetches;    /* wave-level triangle fetches */
+    uint64_t hits_shaded;    /* closest hits whose attributes were resolved and shaded */
+    uint64_t rays_queued;    /* reflection rays written to a device queue */
 } rt_counters;
 
 typedef struct rt_scene rt_scene; /* opaque */
