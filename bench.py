@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X Whitted render path.
+
+Metric (BASELINE.json): Mrays/s (primary + shadow + reflection rays actually
+traversed) at 1920x1080; frame ms; 1/2/4/8-GPU scaling.
+
+Workload (config.workload = "C3"): the dragon-scale stand-in — 819 200-triangle
+torus knot (data/dragon.obj is absent from the reference), 1920x1080, Phong +
+hard shadows + reflections depth 4, default camera — synthetic, generated in
+process. One "step" = one full frame through rt_render_device with the scene,
+BVH and framebuffer resident in HBM.
+
+N GPUs: one process per GPU; the frame's 8-row strips are dealt round-robin to
+the ranks, each renders its strips into a packed buffer, an RCCL all-gather
+over xGMI assembles them and a de-interleave kernel writes the reference's
+row-flipped frame (strong scaling: the frame is fixed).
+
+JSON line (rank 0): the contract's keys plus
+  roofline      dominant kernel k_trace_level: ALGORITHMIC bytes per launch
+                 / average launch duration measured with HIP
+                events on the launch stream during the timed steps; peak 8 TB/s.
+  cpu_baseline  the CPU oracle (kind "port": the repo's restatement of the
+                reference path, OpenMP rows) timed on this host on the same frame.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STRIP_ROWS = 8
+
+
+def algorithmic_bytes(cnt: dict, features, pixels: int) -> dict:
+    """32 B per box test (24 B AABB + 8 B child meta), 36 B per
+    triangle test (three fp32 positions), 16 B per sphere test; per shaded hit
+    32 B material (+36 B normals with normalInterp, +24 B uvs +12 B texel with
+    textures) and its 12 B direct-colour write; 2 x 32 B per queued reflection ray
+    (written by one level, read by the next); 12 B per pixel for the frame write
+    (k_fold, not part of the trace kernel's figure)."""
+    trav = 32 * cnt["box_tests"] + 36 * cnt["tri_tests"] + 16 * cnt["sphere_tests"]
+    per_hit = 32 + 12 + (36 if features.enableNormalInterp else 0) + (36 if features.enableTextureMapping else 0)
+    shade = per_hit * cnt["hits_shaded"]
+    queue = 64 * cnt["rays_queued"]
+    return {"trace_kernel": trav + shade + queue, "frame": trav + shade + queue + 12 * pixels}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-events", action="store_true",
+                    help="do not bracket trace kernels with HIP events during the timed steps")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    capi = importlib.import_module("computer-graphics-engine_amd.capi")
+    scenes = importlib.import_module("computer-graphics-engine_amd.scenes")
+    sharding = importlib.import_module("computer-graphics-engine_amd.sharding")
+
+    rt = capi.Library()
+    rt.set_device(local_rank)
+    ndev, devname = rt.device_info()
+
+    cfg = scenes.CONFIGS[args.workload]
+    W, H = cfg.width, cfg.height
+    f, p = cfg.make_features(), cfg.make_params()
+    data = scenes.get_scene(cfg.scene)
+    t0 = time.time()
+    scene = rt.scene(data)
+    bvh = rt.bvh(scene, f)
+    build_s = time.time() - t0
+    cam = rt.camera(*scenes.default_camera_args(W, H))
+
+    stream = torch.cuda.current_stream().cuda_stream
+    renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, rank, world, strip_rows=STRIP_ROWS)
+
+    # ---- untimed counting pass: rays and tests of THIS rank's strips ------------
+    cnt = renderer.count_rays(stream)
+    keys = list(cnt.keys())
+    cvec = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(cvec)
+    total = dict(zip(keys, [int(v) for v in cvec.tolist()]))
+    rays_per_frame = total["rays"]
+
+    # ---- warmup ----------------------------------------------------------------
+    for _ in range(args.warmup):
+        renderer.step(stream)
+    torch.cuda.synchronize()
+
+    # ---- timed steps -----------------------------------------------------------
+    use_events = not args.no_profile_events
+    rt.profile_enable(bvh, use_events)
+    if use_events:
+        rt.profile_read(bvh, stream, reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        renderer.step(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms, launches = rt.profile_read(bvh, stream, reset=True) if use_events else (0.0, 0)
+    rt.profile_enable(bvh, False)
+    tvec = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tvec, op=dist.ReduceOp.MAX)
+    elapsed = float(tvec.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = rays_per_frame * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        ab = algorithmic_bytes(total, f, W * H)
+        n_levels = (cfg.depth + 1) if f.enableRecursive else 1
+        roofline = None
+        if use_events and launches:
+            # this rank's share of the algorithmic bytes / its own kernel time
+            ab_rank = algorithmic_bytes(cnt, f, 0)["trace_kernel"]
+            per_launch_bytes = ab_rank / n_levels
+            avg_launch_s = kernel_ms / 1e3 / launches
+            achieved = per_launch_bytes / avg_launch_s / 1e9
+            traffic = None
+            tj = ROOT / "profiles" / "hbm_traffic.json"
+            if tj.exists():
+                tr = json.load(open(tj))
+                if tr.get("workload") == args.workload and world == 1:
+                    traffic = tr.get("hbm_bytes_per_launch")
+            roofline = {"bound": "hbm", "kernel": "k_trace_level", "achieved": round(achieved, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                        "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": launches,
+                        "launches_per_frame": n_levels}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, data, scenes)
+        out = {
+            "metric": "Mrays/s (primary+shadow+reflect) at 1920x1080",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene": data.name, "triangles": data.n_triangles,
+                       "resolution": [W, H], "depth": cfg.depth, "features": cfg.features,
+                       "rays_per_frame": rays_per_frame, "rays_reference_equivalent": total["rays_ref_equiv"],
+                       "rays_primary": total["rays_primary"], "rays_shadow": total["rays_shadow"],
+                       "rays_reflect": total["rays_reflect"], "box_tests": total["box_tests"],
+                       "tri_tests": total["tri_tests"], "node_fetches": total["node_fetches"],
+                       "tri_fetches": total["tri_fetches"], "algorithmic_bytes_per_frame": ab["frame"],
+                       "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather" if world > 1 else ""),
+                       "device": devname, "bvh_build_s": round(build_s, 3)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, data, scenes):
+    """The CPU oracle (restatement of the reference path; traces reflections twice
+    like the reference) on the same frame, all host threads. Bounded sample: every
+    `stride`-th 8-row strip of the frame so the run stays within ~10-30 s."""
+    from oracle.cpu_oracle import Oracle
+
+    orc = Oracle()
+    f, p = cfg.make_features(), cfg.make_params()
+    ob = orc.build(data, f)
+    cam = orc.camera(*scenes.default_camera_args(cfg.width, cfg.height))
+    threads = orc.max_threads()
+    # calibrate on the central strip, then size the sample to ~15 s
+    mid = (cfg.height // 2 // 8) * 8
+    t0 = time.perf_counter()
+    _, _, _, c0 = orc.render(ob, cam, f, p, cfg.width, cfg.height, rows=(mid, mid + 8))
+    dt0 = max(time.perf_counter() - t0, 1e-3)
+    n_strips = cfg.height // 8
+    budget_strips = max(1, int(15.0 / dt0))
+    stride = max(1, -(-n_strips // budget_strips))
+    rays, secs, used = 0, 0.0, 0
+    for s in range(0, n_strips, stride):
+        t0 = time.perf_counter()
+        _, _, _, c = orc.render(ob, cam, f, p, cfg.width, cfg.height, rows=(s * 8, s * 8 + 8))
+        secs += time.perf_counter() - t0
+        rays += c.rays
+        used += 1
+    return {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{used} of {n_strips} 8-row strips of the same {cfg.width}x{cfg.height} frame "
+                      f"(every {stride}th), {rays} rays in {secs:.1f} s, OpenMP {threads} threads",
+            "rays": int(rays), "seconds": round(secs, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips",
-    "rt_rand31",
+    "rt_rand31", "rt_profile_enable", "rt_profile_read",
 ]
 
 
@@ -99,6 +99,14 @@ class Bvh:
 class Library:
     def __init__(self, build: bool = True):
         path = build_library() if build else LIB_PATH
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.
+        # Importing torch first makes the loader bind this library's NEEDED
+        # libamdhip64.so.7 to the copy torch already mapped, so device pointers and
+        # streams of torch tensors are valid here (two runtimes cannot share a GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.c = C.CDLL(str(path))
         c = self.c
         c.rt_last_error.restype = C.c_char_p
@@ -127,6 +135,8 @@ class Library:
                                          C.POINTER(abi.Counters)]
         c.rt_deinterleave_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_void_p]
+        c.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        c.rt_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         c.rt_rand31.restype = C.c_uint32
         c.rt_rand31.argtypes = [C.c_uint32] * 6
 
@@ -213,6 +223,16 @@ class Library:
                             stream: int = 0):
         self._check(self.c.rt_deinterleave_strips(C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), width, height,
                                                   strip_rows, n_ranks, C.c_void_p(stream) if stream else None))
+
+    def profile_enable(self, bvh: Bvh, enable: bool):
+        self._check(self.c.rt_profile_enable(bvh.handle, 1 if enable else 0))
+
+    def profile_read(self, bvh: Bvh, stream: int = 0, reset: bool = True):
+        """(summed k_trace_level milliseconds, launches) since the last reset; synchronises the stream."""
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.c.rt_profile_read(bvh.handle, C.c_void_p(stream) if stream else None, C.byref(ms),
+                                           C.byref(n), 1 if reset else 0))
+        return ms.value, int(n.value)
 
     def rand31(self, seed, pixel, level, light, sample, dim) -> int:
         return int(self.c.rt_rand31(seed, pixel, level, light, sample, dim))

@@ -87,6 +87,16 @@ struct Scratch {
     DevBuf<uint32_t> t_bits;
     DevBuf<int32_t> prim;
     DevBuf<rt_counters> counters;
+    // rt_profile_*: event pairs around k_trace_level launches
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    ~Scratch()
+    {
+        for (auto& e : events) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    }
 };
 
 } // namespace
@@ -109,6 +119,7 @@ struct rt_bvh {
     DevBuf<rt::NodePair> nodes;
     DevBuf<rt::PrimRecord> prims;
     std::mutex mu;
+    bool profile = false;
     std::map<void*, std::unique_ptr<Scratch>> scratch; // keyed by stream
     Scratch& scratch_for(void* stream)
     {
@@ -248,7 +259,20 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
         const int ob = level & 1;
         a.out = rt::RaySoA { sc.qray[ob].p, nullptr, sc.qitem[ob].p, sc.qpixel[ob].p, n_items };
         a.out_count = sc.counts.p + level + 1;
+        if (bvh->profile) {
+            if (sc.events_used == sc.events.size()) {
+                hipEvent_t e0, e1;
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventCreate(&e1));
+                sc.events.emplace_back(e0, e1);
+            }
+            HIP_TRY(hipEventRecord(sc.events[sc.events_used].first, stream));
+        }
         rt::launch_trace_level(a, counters_dev != nullptr, stream);
+        if (bvh->profile) {
+            HIP_TRY(hipEventRecord(sc.events[sc.events_used].second, stream));
+            sc.events_used++;
+        }
     }
     fold.direct = sc.direct.p;
     fold.state = sc.state.p;
@@ -626,6 +650,36 @@ int rt_intersect_batch(const rt_bvh* cbvh, rt_ray* rays, uint32_t n_rays, const 
         HIP_TRY(hipMemcpy(hits, sc.hits.p, (size_t)n_rays * sizeof(rt_hit), hipMemcpyDeviceToHost));
     if (counters)
         HIP_TRY(hipMemcpy(counters, sc.counters.p, sizeof(rt_counters), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_profile_enable(rt_bvh* bvh, int enable)
+{
+    if (!bvh)
+        return fail(RT_ERR_INVALID, "rt_profile_enable: null bvh");
+    bvh->profile = enable != 0;
+    return RT_OK;
+}
+
+int rt_profile_read(rt_bvh* bvh, void* hip_stream, double* trace_kernel_ms, uint64_t* trace_kernel_launches,
+    int reset)
+{
+    if (!bvh)
+        return fail(RT_ERR_INVALID, "rt_profile_read: null bvh");
+    Scratch& sc = bvh->scratch_for(hip_stream);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    double ms = 0.0;
+    for (size_t i = 0; i < sc.events_used; i++) {
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, sc.events[i].first, sc.events[i].second));
+        ms += t;
+    }
+    if (trace_kernel_ms)
+        *trace_kernel_ms = ms;
+    if (trace_kernel_launches)
+        *trace_kernel_launches = sc.events_used;
+    if (reset)
+        sc.events_used = 0;
     return RT_OK;
 }
 

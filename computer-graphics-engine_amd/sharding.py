@@ -1,0 +1,94 @@
+"""Multi-GPU frame sharding: pixel-row strips across ranks, RCCL gather over xGMI.
+
+The reference's only parallelism is image-space: OpenMP over rows
+(src/render.cpp:277-281) writing one shared Screen. Here every pixel is still
+independent; scene and BVH are replicated per GPU, 8-row strips are dealt
+round-robin to the ranks (balances an object in the middle of the frame; row
+blocks would not), each rank renders its strips into a packed buffer, ONE
+exchange step — an all-gather of equal-sized packed buffers — assembles them,
+and rt_deinterleave_strips writes the reference's row-flipped frame. The
+area-light RNG is keyed by the global pixel id, so the image does not depend on
+the number of ranks. torch.distributed is plumbing here (backend "nccl" = RCCL
+on ROCm; "gloo" in the CPU tests of the partition logic).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+
+
+def strip_rows_of_rank(height: int, strip_rows: int, rank: int, world: int) -> np.ndarray:
+    """Image rows (the reference's loop variable y) rendered by `rank`."""
+    n_strips = -(-height // strip_rows)
+    rows: List[int] = []
+    for s in range(rank, n_strips, world):
+        rows.extend(range(s * strip_rows, min((s + 1) * strip_rows, height)))
+    return np.asarray(rows, np.int32)
+
+
+def rows_max(height: int, strip_rows: int, world: int) -> int:
+    """Packed rows per rank in the gathered buffer (the largest share)."""
+    n_strips = -(-height // strip_rows)
+    return -(-n_strips // world) * strip_rows
+
+
+def deinterleave_numpy(gathered: np.ndarray, height: int, strip_rows: int) -> np.ndarray:
+    """Host statement of rt_deinterleave_strips (used by the CPU tests):
+    gathered[rank, local_row, x, 3] → row-flipped frame[H, W, 3]."""
+    world, _, width, _ = gathered.shape
+    frame = np.zeros((height, width, 3), gathered.dtype)
+    for y in range(height):
+        strip = y // strip_rows
+        rank = strip % world
+        lrow = (strip // world) * strip_rows + (y - strip * strip_rows)
+        frame[height - 1 - y] = gathered[rank, lrow]
+    return frame
+
+
+class StripRenderer:
+    """One rank's share of a frame + the gather. `step()` enqueues everything on
+    the given HIP stream without host synchronisation."""
+
+    def __init__(self, rt, bvh, cam, features, params, width, height, rank=0, world=1, strip_rows=8):
+        import torch
+
+        self.rt, self.bvh, self.cam, self.f, self.p = rt, bvh, cam, features, params
+        self.W, self.H, self.rank, self.world, self.strip_rows = width, height, rank, world, strip_rows
+        self.rows = strip_rows_of_rank(height, strip_rows, rank, world)
+        self.frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+        self.counters = torch.zeros(16, dtype=torch.int64, device="cuda")
+        if world > 1:
+            rmax = rows_max(height, strip_rows, world)
+            self.local = torch.zeros((rmax, width, 3), dtype=torch.float32, device="cuda")
+            self.gathered = torch.zeros((world, rmax, width, 3), dtype=torch.float32, device="cuda")
+
+    def step(self, stream: int = 0):
+        if self.world == 1:
+            self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
+                                  stream=stream)
+            return
+        import torch.distributed as dist
+
+        self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local.data_ptr(),
+                              rows=self.rows, packed=True, stream=stream)
+        dist.all_gather_into_tensor(self.gathered, self.local)
+        self.rt.deinterleave_strips(self.gathered.data_ptr(), self.frame.data_ptr(), self.W, self.H,
+                                    self.strip_rows, self.world, stream=stream)
+
+    def count_rays(self, stream: int = 0) -> dict:
+        """One untimed frame of this rank's rows with the counting kernels."""
+        import torch
+
+        abi = __import__("importlib").import_module("computer-graphics-engine_amd.abi")
+        self.counters.zero_()
+        if self.world == 1:
+            self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
+                                  counters_ptr=self.counters.data_ptr(), stream=stream)
+        else:
+            self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local.data_ptr(),
+                                  rows=self.rows, packed=True, counters_ptr=self.counters.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        vals = self.counters.cpu().numpy().view(np.uint64)
+        names = [n for n, _ in abi.Counters._fields_]
+        return {n: int(vals[i]) for i, n in enumerate(names)}

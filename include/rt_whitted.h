@@ -255,6 +255,15 @@ int rt_trace_batch(const rt_bvh* bvh, const rt_ray* rays, uint32_t n_rays, const
 int rt_intersect_batch(const rt_bvh* bvh, rt_ray* rays, uint32_t n_rays, const rt_features* features,
                        rt_hit* hits, rt_counters* counters);
 
+/* -- Instrumentation for the roofline figure (bench.py): when enabled on a bvh,
+ *    every k_trace_level launch of later rt_render_device calls is bracketed by
+ *    hipEvents recorded on the launch stream. rt_profile_read synchronises the
+ *    stream and returns the summed kernel milliseconds and the launch count since
+ *    the last reset. Off by default; costs two event records per launch. ------- */
+int rt_profile_enable(rt_bvh* bvh, int enable);
+int rt_profile_read(rt_bvh* bvh, void* hip_stream, double* trace_kernel_ms, uint64_t* trace_kernel_launches,
+                    int reset);
+
 /* -- Multi-GPU strip de-interleave: gathered packed strips
  *    of all ranks → the reference's row-flipped frame. gathered_dev holds
  *    n_ranks blocks of rows_per_rank_max*W*3 floats; strip s (strip_rows image
