@@ -247,9 +247,10 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
     max_leaf = 0;
     const int32_t root = b.create(0, n, 0);
 
-    // permutation + fetch records
+    // permutation (reference array order) + fetch records in that order
     prim_order.resize(n);
-    records.resize(n);
+    std::vector<PrimRecord> flat(n);
+    std::vector<PrimRecord>& records = flat;
     // which mesh does a triangle prim id belong to
     std::vector<uint32_t> mesh_of(scene.n_triangles);
     for (uint32_t m = 0; m < scene.meshes.size(); m++)
@@ -281,6 +282,32 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
         }
     }
 
+    // Device order = the order in which the reference's traversal reaches the
+    // primitives when every box is hit: the stack pops the RIGHT child first
+    // (bvh.cpp:354-355), leaf primitives in array order (:272-293). With this
+    // order "tested later" == "larger index", which is all the order-free
+    // closest-hit reduction of rt_device.h needs.
+    std::vector<uint32_t> leaf_dev_beg(nodes.size(), 0);
+    this->records.clear();
+    this->records.reserve(n);
+    {
+        std::vector<int32_t> stack { root };
+        while (!stack.empty()) {
+            const int32_t i = stack.back();
+            stack.pop_back();
+            const RefNode& nd = nodes[i];
+            if (nd.leaf) {
+                leaf_dev_beg[i] = (uint32_t)this->records.size();
+                for (int32_t p = nd.beg; p < nd.end; p++)
+                    this->records.push_back(flat[p]);
+            } else {
+                stack.push_back(nd.left);
+                stack.push_back(nd.right);
+            }
+        }
+    }
+    records_flat.swap(flat);
+
     // NodePair per internal node; child reference of a node
     std::vector<int32_t> pair_of(nodes.size(), -1);
     pairs.clear();
@@ -292,7 +319,7 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
     auto child_ref = [&](int32_t node, uint32_t& ref, uint32_t& cnt) {
         const RefNode& c = nodes[node];
         if (c.leaf)
-            ref = (uint32_t)c.beg, cnt = (uint32_t)(c.end - c.beg);
+            ref = leaf_dev_beg[node], cnt = (uint32_t)(c.end - c.beg);
         else
             ref = (uint32_t)pair_of[node], cnt = 0;
     };

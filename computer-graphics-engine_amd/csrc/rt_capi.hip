@@ -117,7 +117,7 @@ struct rt_bvh {
     rt_scene* scene = nullptr;
     rt::HostBvh host;
     DevBuf<rt::NodePair> nodes;
-    DevBuf<rt::PrimRecord> prims;
+    DevBuf<rt::PrimRecord> prims, prims_flat;
     std::mutex mu;
     bool profile = false;
     std::map<void*, std::unique_ptr<Scratch>> scratch; // keyed by stream
@@ -134,6 +134,7 @@ struct rt_bvh {
         rt::SceneView v;
         v.nodes = nodes.p;
         v.prims = prims.p;
+        v.prims_flat = prims_flat.p;
         v.tri_vidx = scene->tri_vidx.p;
         v.vnormal = scene->vnormal.p;
         v.vtexcoord = scene->vtexcoord.p;
@@ -397,6 +398,7 @@ int rt_bvh_build(rt_scene* scene, const rt_features* features, rt_bvh** out)
         return fail(RT_ERR_INVALID, "rt_bvh_build: " + err);
     HIP_TRY(b->nodes.upload(b->host.pairs));
     HIP_TRY(b->prims.upload(b->host.records));
+    HIP_TRY(b->prims_flat.upload(b->host.records_flat));
     *out = b.release();
     return RT_OK;
 }

@@ -1,19 +1,33 @@
 // rt_device.h — device-side building blocks of the Whitted path (gfx950).
 //
-// One wavefront lane = one ray. A WAVE walks the BVH as a packet: the visit
-// order of the reference's traversal (src/bounding_volume_hierarchy.cpp:312-362)
-// is fixed — push left, push right, pop right first — and never depends on the
-// ray or on the closest hit so far (ray.t is reset to FLT_MAX around every box
-// test, :334-352). The set of nodes a ray visits is therefore purely geometric,
-// and every lane's visit sequence is a subsequence of one fixed DFS order. The
-// wave walks the UNION of its lanes' visit sets in that order, carrying a
-// 64-bit lane mask per stack entry; a lane takes part in a node exactly when
-// the reference would have visited it for that lane's ray, so per-ray results
-// (t bits, last-accepted primitive on ties) are those of the scalar reference.
-// What the packet buys on CDNA4: node and primitive records are fetched once
-// per wave with scalar (SMEM) loads through the constant address space instead
-// of 64 divergent vector loads, control flow is wave-uniform, and the traversal
-// stack is 4 VGPRs used as a lane-indexed array (slot i lives in lane i).
+// One wavefront lane = one ray. Why the traversal below may reorder work and
+// still return the reference's bits:
+//
+//   * The reference never prunes: ray.t is reset to FLT_MAX around every box test
+//     (src/bounding_volume_hierarchy.cpp:334-352), so the set of leaves a ray
+//     visits is purely geometric — it does not depend on hits found so far.
+//   * Within that set the reference tests primitives in a FIXED order (push left,
+//     push right, pop right first; leaf primitives in array order) and accepts a
+//     triangle when 0 <= t <= ray.t and the point is inside (Appendix A.2), the
+//     last accepted one being reported (bvh.cpp:272-293). The inside test and t
+//     depend on the triangle and the ray only, so the final result is: ray.t =
+//     min t over the candidates (inside, 0 <= t <= initial ray.t), and the hit
+//     primitive is the LAST candidate in the fixed order that attains that
+//     minimum (an equal t is accepted again: "<="). Spheres use a strict "<"
+//     (A.3), so among equal minima a sphere only wins when no triangle attains
+//     the minimum, and then the FIRST such sphere does.
+//
+// Hence closest-hit = min over candidates of the key (t, tie rank) — a reduction
+// that is independent of evaluation order. The host stores primitives in the
+// reference's visit order (rt_layout.h), so "later in the fixed order" is simply
+// "larger array index", and the kernel is free to:
+//   - walk each ray's tree depth-first with a per-lane stack in LDS (node phase),
+//   - park every (ray, leaf) pair it finds in a per-wave LDS queue, and
+//   - test leaves in a separate phase where HALF A WAVE works on ONE pair, one
+//     triangle per lane: consecutive lanes read consecutive 96-byte records
+//     (coalesced), the ray is an LDS broadcast, and a candidate lane publishes
+//     its key with one 64-bit LDS atomic-min. Shadow rays (any-hit) stop as soon
+//     as their slot holds a key.
 //
 // Arithmetic: every float op is a separately rounded IEEE binary32 op in the
 // reference's order (file built with -ffp-contract=off; '/' and sqrtf are
@@ -26,11 +40,13 @@
 
 namespace rt {
 
-#define RT_CONST_AS __attribute__((address_space(4)))
 #define RT_DEV __device__ __forceinline__
+// constant address space: a wave-uniform index into such a pointer becomes scalar (SMEM) loads
+#define RT_CONST_AS __attribute__((address_space(4)))
 
 constexpr float kFltMax = 3.402823466e+38f;
 constexpr float kFltMin = 1.175494351e-38f;
+constexpr unsigned long long kNoHit = ~0ull;
 
 struct V3 {
     float x, y, z;
@@ -52,6 +68,7 @@ RT_DEV bool all_zero(V3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
 // second operand wins when the compare is false/unordered (x86 minss/maxss)
 RT_DEV float sel_min(float a, float b) { return a < b ? a : b; }
 RT_DEV float sel_max(float a, float b) { return a > b ? a : b; }
+RT_DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 
 struct RayL { // one lane's ray
     V3 o, d;
@@ -60,44 +77,45 @@ struct RayL { // one lane's ray
 // ---- wave helpers ---------------------------------------------------------
 RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 RT_DEV uint64_t ballot(bool p) { return __ballot(p); }
-RT_DEV bool lane_in(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 RT_DEV uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 RT_DEV uint32_t prefix_count(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-
-// Lane-indexed wave stack: entry i = {ref, cnt, mask} stored in lane i of four VGPRs.
-struct WaveStack {
-    uint32_t ref, cnt, mlo, mhi;
-    RT_DEV void push(uint32_t lane, uint32_t sp, uint32_t r, uint32_t c, uint64_t m)
-    {
-        const bool here = lane == sp;
-        ref = here ? r : ref;
-        cnt = here ? c : cnt;
-        mlo = here ? (uint32_t)m : mlo;
-        mhi = here ? (uint32_t)(m >> 32) : mhi;
-    }
-    RT_DEV void pop(uint32_t sp, uint32_t& r, uint32_t& c, uint64_t& m) const
-    {
-        r = (uint32_t)__builtin_amdgcn_readlane((int)ref, (int)sp);
-        c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)sp);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)sp);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)sp);
-        m = ((uint64_t)hi << 32) | lo;
-    }
-};
+RT_DEV uint32_t read_lane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// lanes of one wave exchange data through LDS: keep the compiler from moving LDS
+// accesses across the hand-over (the hardware runs one wave's LDS ops in order)
+RT_DEV void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 struct LaneCounters {
     uint32_t box = 0, tri = 0, sph = 0;     // lane-level tests
-    uint32_t node_fetch = 0, tri_fetch = 0; // wave-level record fetches (same value in every lane)
+    uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
 };
+
+// Per-wave LDS working set (8 KiB): ray table, best-key slots, the per-lane DFS
+// stacks (slot [level][lane]: conflict-free) and the (ray, leaf) pair queue.
+constexpr uint32_t kStackLevels = 16; // MAX_DEPTH = 16 levels ⇒ at most 15 internal levels pending
+constexpr uint32_t kLeafQueue = 192;  // < 64 left over + at most 128 appended per node step
+struct alignas(16) WaveLds {
+    float4 rayA[64]; // ox oy oz dx
+    float4 rayB[64]; // dy dz t0 -
+    unsigned long long best[64];
+    uint32_t stack[kStackLevels][64];
+    uint32_t lq_ref[kLeafQueue];
+    uint32_t lq_rc[kLeafQueue]; // ray lane (6 bits) | count << 6
+};
+static_assert(sizeof(WaveLds) == 8192, "WaveLds");
 
 // ---- primitive tests (decls src/intersect.h:5-16) -----
 
 // A.4 intersectRayWithShape(AxisAlignedBox) with ray.t = FLT_MAX (bvh.cpp:336,344):
-// only the boolean matters. lo/hi are wave-uniform (SGPR) box bounds.
-RT_DEV bool box_hit(const float RT_CONST_AS* lo, const float RT_CONST_AS* hi, const RayL& r)
+// only the boolean matters.
+RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r)
 {
     float tl[3], th[3];
     const float o[3] = { r.o.x, r.o.y, r.o.z };
@@ -125,159 +143,253 @@ RT_DEV bool box_hit(const float RT_CONST_AS* lo, const float RT_CONST_AS* hi, co
     return true;
 }
 
-// A.1 + A.2 with the per-triangle part (n, D, edge vectors) read from the record.
-// Returns true and updates t when the reference would accept (0 <= t' <= t, inside).
-RT_DEV bool tri_hit(const PrimRecord RT_CONST_AS* rec, const RayL& r, float& t)
+// A.2: t of the ray with the triangle's plane (n, D precomputed on the host with
+// the same operation order — rt_layout.h)
+RT_DEV float tri_plane_t(const PrimRecord& rec, const RayL& r)
 {
-    const V3 n = mk(rec->n[0], rec->n[1], rec->n[2]);
-    const float tt = (rec->D - dot(r.o, n)) / dot(r.d, n);
+    const V3 n = mk(rec.n[0], rec.n[1], rec.n[2]);
+    return (rec.D - dot(r.o, n)) / dot(r.d, n);
+}
+
+// A.1 + A.2: is this triangle a candidate for a ray whose limit is t0?
+// (0 <= t <= t0 and the three inclusive edge tests, in the reference's order)
+RT_DEV bool tri_candidate(const PrimRecord& rec, const RayL& r, float t0, float& tt)
+{
+    tt = tri_plane_t(rec, r);
     if (!(tt >= 0.0f))
         return false;
-    if (!(t >= tt))
+    if (!(t0 >= tt))
         return false;
     const V3 p = r.d * tt + r.o;
-    if (!(dot(mk(rec->e0[0], rec->e0[1], rec->e0[2]), p - mk(rec->v0[0], rec->v0[1], rec->v0[2])) >= 0.0f))
+    if (!(dot(ld3(rec.e0), p - ld3(rec.v0)) >= 0.0f))
         return false;
-    if (!(dot(mk(rec->e1[0], rec->e1[1], rec->e1[2]), p - mk(rec->v1[0], rec->v1[1], rec->v1[2])) >= 0.0f))
+    if (!(dot(ld3(rec.e1), p - ld3(rec.v1)) >= 0.0f))
         return false;
-    if (!(dot(mk(rec->e2[0], rec->e2[1], rec->e2[2]), p - mk(rec->v2[0], rec->v2[1], rec->v2[2])) >= 0.0f))
+    if (!(dot(ld3(rec.e2), p - ld3(rec.v2)) >= 0.0f))
         return false;
-    t = tt;
     return true;
 }
 
 // A.3 intersectRayWithShape(Sphere): assumes |direction| = 1, strict t < ray.t
-RT_DEV bool sphere_hit(const PrimRecord RT_CONST_AS* rec, const RayL& r, float& t)
+RT_DEV bool sphere_candidate(const PrimRecord& rec, const RayL& r, float t0, float& tt)
 {
-    const V3 c = mk(rec->v0[0], rec->v0[1], rec->v0[2]);
-    const float radius = rec->D;
+    const V3 c = ld3(rec.v0);
+    const float radius = rec.D;
     const V3 oc = r.o - c;
     const float h = dot(r.d, oc);
     const float B = h + h;
     const float C = dot(oc, oc) - radius * radius;
     const float disc = B * B - C * 4.0f;
+    tt = kFltMax;
     if (disc < 0.0f)
         return false;
-    float t0, t1;
+    float t0r, t1r;
     if (disc == 0.0f) {
-        t0 = t1 = 0.5f * (-B);
+        t0r = t1r = 0.5f * (-B);
     } else {
         const float q = sqrtf(disc);
-        t1 = (q - B) * 0.5f;
-        t0 = ((-B) - q) * 0.5f;
+        t1r = (q - B) * 0.5f;
+        t0r = ((-B) - q) * 0.5f;
     }
-    float tt = kFltMax;
-    if (t1 >= 0.0f) {
-        if (t0 >= 0.0f)
-            tt = sel_min(t0, t1);
-        else if (t1 <= kFltMax)
-            tt = t1;
-    } else if (t0 >= 0.0f && t0 < kFltMax) {
-        tt = t0;
+    if (t1r >= 0.0f) {
+        if (t0r >= 0.0f)
+            tt = sel_min(t0r, t1r);
+        else if (t1r <= kFltMax)
+            tt = t1r;
+    } else if (t0r >= 0.0f && t0r < kFltMax) {
+        tt = t0r;
     }
-    if (tt < 0.0f || tt >= t)
+    if (tt < 0.0f || tt >= t0)
         return false;
-    t = tt;
     return true;
 }
 
-// ---- packet traversal -------------------------------------------------------
-// ANY = false: closest hit, ≙ the traversal part of BoundingVolumeHierarchy::intersect
-//   (bvh.cpp:299-362) + getIntersecting (:272-293). `t` holds ray.t in/out, `pos`
-//   receives the permuted index of the last accepted primitive (-1: none).
-// ANY = true: shadow query — the reference runs the same closest-hit traversal and
-//   only uses the boolean (light.cpp:61-67); a lane leaves the packet at its first
-//   accepted primitive. `t` is the ray's t limit (1.0 for shadow rays).
-// `active` selects the lanes that carry a ray; all lanes of the wave must call.
-// use_bvh = features.enableAccelStructure; when false every primitive is tested
-// in permuted order (bvh.cpp:303-305).
+// 64-bit reduction key: smaller = better. High word: t bits (t >= 0, so unsigned
+// order = float order; -0.0f is folded onto +0.0f because the reference compares
+// them equal). Low word: triangles first (bit 31 clear), larger index = smaller
+// key ("last accepted wins"); spheres after them, smaller index first.
+RT_DEV unsigned long long make_key(float tt, uint32_t index, bool sphere)
+{
+    const uint32_t tb = tt == 0.0f ? 0u : __float_as_uint(tt);
+    const uint32_t low = sphere ? (0x80000000u | index) : (0x7fffffffu - index);
+    return ((unsigned long long)tb << 32) | low;
+}
+RT_DEV uint32_t key_index(unsigned long long key)
+{
+    const uint32_t low = (uint32_t)key;
+    return (low & 0x80000000u) ? (low & 0x7fffffffu) : (0x7fffffffu - low);
+}
+
+// ---- leaf phase -----------------------------------------------------------------
+// Entries [first, first + n) of the wave's leaf queue, n <= 64: two entries per
+// step, one per half-wave, one primitive per lane.
 template <bool ANY, bool COUNT>
-RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool active, const RayL& ray, float& t, int32_t& pos,
+RT_DEV void leaf_phase(WaveLds& L, const PrimRecord* __restrict__ prims, uint32_t first, uint32_t n, uint32_t lane,
     LaneCounters& lc)
 {
-    pos = -1;
-    uint64_t alive = ballot(active);
-    if (alive == 0)
-        return;
-    const uint32_t lane = lane_id();
-    WaveStack st { 0u, 0u, 0u, 0u };
-    uint32_t sp = 0;
-    uint32_t ref = use_bvh ? sv.root_ref : 0u;
-    uint32_t cnt = use_bvh ? sv.root_cnt : sv.n_prims;
-    uint64_t mask = alive;
-    const NodePair RT_CONST_AS* nodes = (const NodePair RT_CONST_AS*)sv.nodes;
-    const PrimRecord RT_CONST_AS* prims = (const PrimRecord RT_CONST_AS*)sv.prims;
-
-    for (;;) {
-        if (cnt == 0u) {
-            // internal node: test both children's boxes for the lanes in `mask`
-            const NodePair RT_CONST_AS* np = nodes + ref;
-            const bool in = lane_in(mask);
-            bool hl = false, hr = false;
-            if (in) {
-                hl = box_hit(np->l_lo, np->l_hi, ray);
-                hr = box_hit(np->r_lo, np->r_hi, ray);
-                if (COUNT)
-                    lc.box += 2;
-            }
-            if (COUNT)
-                lc.node_fetch++;
-            const uint64_t ml = ballot(hl), mr = ballot(hr);
-            const uint32_t l_ref = np->l_ref, l_cnt = np->l_cnt, r_ref = np->r_ref, r_cnt = np->r_cnt;
-            if (mr) { // right child is popped first (bvh.cpp:354-355)
-                if (ml) {
-                    st.push(lane, sp, l_ref, l_cnt, ml);
-                    sp++;
+    uint32_t my_ref = 0, my_rc = 0;
+    if (lane < n) {
+        my_ref = L.lq_ref[first + lane];
+        my_rc = L.lq_rc[first + lane];
+    }
+    const bool upper = lane >= 32u;
+    const uint32_t sub = lane & 31u;
+    for (uint32_t k = 0; k < n; k += 2) {
+        const uint32_t ref0 = read_lane(my_ref, k), rc0 = read_lane(my_rc, k);
+        const uint32_t ref1 = read_lane(my_ref, k + 1), rc1 = (k + 1 < n) ? read_lane(my_rc, k + 1) : 0u;
+        const uint32_t ref = upper ? ref1 : ref0;
+        const uint32_t rc = upper ? rc1 : rc0;
+        const uint32_t r = rc & 63u, cnt = rc >> 6;
+        const uint32_t c0 = rc0 >> 6, c1 = rc1 >> 6;
+        const uint32_t cmax = c0 > c1 ? c0 : c1;
+        for (uint32_t base = 0; base < cmax; base += 32u) {
+            const uint32_t idx = base + sub;
+            if (idx < cnt) {
+                if (ANY && L.best[r] != kNoHit)
+                    continue; // this shadow ray is already blocked
+                const float4 a = L.rayA[r], b = L.rayB[r];
+                RayL ray;
+                ray.o = mk(a.x, a.y, a.z);
+                ray.d = mk(a.w, b.x, b.y);
+                const float t0 = b.z;
+                const uint32_t index = ref + idx;
+                const PrimRecord rec = prims[index];
+                float tt;
+                bool cand;
+                const bool sphere = (rec.kind_mat & 0x80000000u) != 0u;
+                if (!sphere) {
+                    cand = tri_candidate(rec, ray, t0, tt);
+                    if (COUNT)
+                        lc.tri++;
+                } else {
+                    cand = sphere_candidate(rec, ray, t0, tt);
+                    if (COUNT)
+                        lc.sph++;
                 }
-                ref = r_ref, cnt = r_cnt, mask = mr;
-                continue;
-            }
-            if (ml) {
-                ref = l_ref, cnt = l_cnt, mask = ml;
-                continue;
-            }
-        } else {
-            // leaf: every primitive of [ref, ref+cnt) in order, last accepted wins (bvh.cpp:272-293)
-            const bool in = lane_in(mask);
-            for (uint32_t i = 0; i < cnt; i++) {
-                const PrimRecord RT_CONST_AS* rec = prims + (ref + i);
-                bool hit = false;
                 if (COUNT)
                     lc.tri_fetch++;
-                if ((rec->kind_mat & 0x80000000u) == 0u) {
-                    if (in && (!ANY || pos < 0)) {
-                        hit = tri_hit(rec, ray, t);
-                        if (COUNT)
-                            lc.tri++;
-                    }
-                } else {
-                    if (in && (!ANY || pos < 0)) {
-                        hit = sphere_hit(rec, ray, t);
-                        if (COUNT)
-                            lc.sph++;
-                    }
-                }
-                if (hit)
-                    pos = (int32_t)(ref + i);
-                if (ANY) {
-                    alive &= ~ballot(hit);
-                    if ((mask & alive) == 0)
-                        break;
-                }
+                if (cand)
+                    atomicMin(&L.best[r], make_key(tt, index, sphere));
             }
         }
-        // pop the next entry that still has live lanes
-        for (;;) {
-            if (sp == 0u)
-                return;
+    }
+}
+
+// ---- traversal ------------------------------------------------------------------
+// ANY = false: closest hit ≙ BoundingVolumeHierarchy::intersect's traversal
+//   (bvh.cpp:299-362) + getIntersecting (:272-293): `t` holds ray.t in/out, `pos`
+//   the array index of the reported primitive (-1: none).
+// ANY = true: shadow query (light.cpp:61-67 only uses the boolean): `t` is the
+//   limit (1.0), pos >= 0 iff something blocks the ray.
+// `active` selects the lanes that carry a ray; ALL lanes of the wave must call.
+// use_bvh = features.enableAccelStructure; when false the whole array is one leaf
+// in the reference's own order (bvh.cpp:303-305; sv.prims_flat).
+template <bool ANY, bool COUNT>
+RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool active, const RayL& ray, float& t, int32_t& pos,
+    LaneCounters& lc, WaveLds& L)
+{
+    pos = -1;
+    if (ballot(active) == 0)
+        return;
+    const uint32_t lane = lane_id();
+    const PrimRecord* __restrict__ prims = use_bvh ? sv.prims : sv.prims_flat;
+    L.rayA[lane] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t, 0.0f);
+    L.best[lane] = kNoHit;
+
+    uint32_t sp = 0;   // this lane's stack depth
+    uint32_t lq_n = 0; // leaf-queue fill (wave-uniform)
+    const bool root_is_leaf = !use_bvh || sv.root_cnt != 0u;
+    if (root_is_leaf) {
+        const uint64_t m = ballot(active);
+        if (active) {
+            const uint32_t o = prefix_count(m);
+            L.lq_ref[o] = use_bvh ? sv.root_ref : 0u;
+            L.lq_rc[o] = lane | ((use_bvh ? sv.root_cnt : sv.n_prims) << 6);
+        }
+        lq_n = (uint32_t)__builtin_popcountll(m);
+    } else if (active) {
+        L.stack[0][lane] = sv.root_ref; // the root's own box is never tested (bvh.cpp:313)
+        sp = 1;
+    }
+    wave_lds_fence();
+
+    while (ballot(sp > 0) != 0) {
+        // ---- node phase: every lane with work pops one internal node of ITS ray ----
+        bool leaf_l = false, leaf_r = false;
+        uint32_t l_ref = 0, l_cnt = 0, r_ref = 0, r_cnt = 0;
+        if (sp > 0) {
             sp--;
-            st.pop(sp, ref, cnt, mask);
-            if (ANY)
-                mask &= alive;
-            if (mask != 0)
-                break;
+            const NodePair* np = sv.nodes + L.stack[sp][lane];
+            const float4 q0 = *reinterpret_cast<const float4*>(&np->l_lo[0]); // l_lo xyz, l_hi x
+            const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
+            const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
+            const uint4 q3 = *reinterpret_cast<const uint4*>(&np->l_ref);
+            const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
+            const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
+            const bool hl = box_hit(llo, lhi, ray);
+            const bool hr = box_hit(rlo, rhi, ray);
+            l_ref = q3.x, l_cnt = q3.y, r_ref = q3.z, r_cnt = q3.w;
+            if (COUNT) {
+                lc.box += 2;
+                lc.node_fetch++;
+            }
+            if (hl && l_cnt == 0u) {
+                L.stack[sp][lane] = l_ref;
+                sp++;
+            }
+            if (hr && r_cnt == 0u) {
+                L.stack[sp][lane] = r_ref;
+                sp++;
+            }
+            leaf_l = hl && l_cnt != 0u;
+            leaf_r = hr && r_cnt != 0u;
+        }
+        const uint64_t ml = ballot(leaf_l), mr = ballot(leaf_r);
+        if (ml | mr) {
+            if (leaf_l) {
+                const uint32_t o = lq_n + prefix_count(ml);
+                L.lq_ref[o] = l_ref;
+                L.lq_rc[o] = lane | (l_cnt << 6);
+            }
+            lq_n += (uint32_t)__builtin_popcountll(ml);
+            if (leaf_r) {
+                const uint32_t o = lq_n + prefix_count(mr);
+                L.lq_ref[o] = r_ref;
+                L.lq_rc[o] = lane | (r_cnt << 6);
+            }
+            lq_n += (uint32_t)__builtin_popcountll(mr);
+            if (lq_n >= 64u) {
+                wave_lds_fence();
+                do {
+                    lq_n -= 64u;
+                    leaf_phase<ANY, COUNT>(L, prims, lq_n, 64u, lane, lc);
+                } while (lq_n >= 64u);
+                wave_lds_fence();
+                if (ANY && L.best[lane] != kNoHit)
+                    sp = 0; // blocked: drop the rest of this ray's tree
+            }
         }
     }
+    if (lq_n) {
+        wave_lds_fence();
+        leaf_phase<ANY, COUNT>(L, prims, 0u, lq_n, lane, lc);
+    }
+    wave_lds_fence();
+    const unsigned long long key = L.best[lane];
+    if (active && key != kNoHit) {
+        pos = (int32_t)key_index(key);
+        if (!ANY) { // the reported primitive's own t, with its exact bits (-0.0f included)
+            const PrimRecord rec = prims[pos];
+            float tt;
+            if (rec.kind_mat & 0x80000000u)
+                sphere_candidate(rec, ray, t, tt);
+            else
+                tt = tri_plane_t(rec, ray);
+            t = tt;
+        }
+    }
+    wave_lds_fence(); // the caller may reuse L for the next query
 }
 
 } // namespace rt

@@ -142,10 +142,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_level(const LevelArgs a)
     RayCounts rc;
     if (COUNT && active)
         rc.closest = 1;
+    __shared__ WaveLds lds[kBlock / 64];
+    WaveLds& wl = lds[threadIdx.x >> 6];
 
     // ---- closest hit (bvh.intersect, render.cpp:31) -----------------------------
     int32_t pos;
-    traverse<false, COUNT>(sv, use_bvh, active, ray, t, pos, lc);
+    traverse<false, COUNT>(sv, use_bvh, active, ray, t, pos, lc, wl);
     const bool hit = active && pos >= 0;
     if (active) {
         if (hit)
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_level(const LevelArgs a)
                     int32_t spos;
                     if (COUNT && hit)
                         rc.shadow++;
-                    traverse<true, COUNT>(sv, use_bvh, hit, sray, st, spos, lc);
+                    traverse<true, COUNT>(sv, use_bvh, hit, sray, st, spos, lc, wl);
                     if (spos >= 0)
                         visibility = 0.0f;
                 }
@@ -337,8 +339,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const IntersectArgs a)
     RayCounts rc;
     if (COUNT && active)
         rc.closest = 1;
+    __shared__ WaveLds lds[kBlock / 64];
     int32_t pos;
-    traverse<false, COUNT>(a.sv, (a.flags & F_ACCEL) != 0, active, ray, t, pos, lc);
+    traverse<false, COUNT>(a.sv, (a.flags & F_ACCEL) != 0, active, ray, t, pos, lc, lds[threadIdx.x >> 6]);
     if (active) {
         const bool hit = pos >= 0;
         HitL h;

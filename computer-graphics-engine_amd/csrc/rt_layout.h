@@ -25,7 +25,11 @@ static_assert(sizeof(NodePair) == 64, "NodePair must be one 64-byte record");
 
 enum : uint32_t { PRIM_TRIANGLE = 0u, PRIM_SPHERE = 1u };
 
-// One primitive in BVH (permuted) order. For a triangle the per-primitive part
+// One primitive. Two device arrays hold these records: `prims` in the order in
+// which the reference's traversal would reach them if every box were hit
+// (leaves right-first, src/bounding_volume_hierarchy.cpp:354-355; array order
+// inside a leaf), so that "tested later" == "larger index" (rt_device.h), and
+// `prims_flat` in the reference's own array order for the brute-force path. For a triangle the per-primitive part
 // of intersectRayWithTriangle is hoisted here: it
 // depends on the vertices only, and is computed on the host with the same
 // operation order, so per-ray results stay bit-identical:
@@ -73,7 +77,8 @@ static_assert(sizeof(LightRec) == 96, "LightRec");
 // Device view of a built scene + BVH (all pointers into HBM).
 struct SceneView {
     const NodePair* nodes;
-    const PrimRecord* prims;    // permuted (BVH) order
+    const PrimRecord* prims;      // BVH mode: the reference's visit order (right-first DFS over the leaves)
+    const PrimRecord* prims_flat; // brute-force mode (enableAccelStructure off): the reference's array order
     const uint32_t* tri_vidx;   // prim_id*3 → global vertex index (triangles only)
     const float* vnormal;       // global vertex normals, xyz
     const float* vtexcoord;     // global vertex texcoords, uv

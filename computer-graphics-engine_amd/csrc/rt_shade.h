@@ -24,8 +24,6 @@ struct HitL { // one lane's HitInfo (src/common.h:14-19) without the unused memb
     int32_t texture;
 };
 
-RT_DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
-
 // computeBarycentricCoord — src/interpolate.cpp:4-17
 RT_DEV V3 barycentric(V3 v0, V3 v1, V3 v2, V3 p)
 {
@@ -80,10 +78,10 @@ RT_DEV V3 acquire_texel(const SceneView& sv, int32_t tex, float u, float v, bool
 }
 
 // Hit attribute resolution — src/bounding_volume_hierarchy.cpp:365-426.
-// `pos` is the permuted index of the final primitive; returns its prim id.
+// `pos` is the array index of the reported primitive; returns its prim id.
 RT_DEV int32_t resolve_hit(const SceneView& sv, uint32_t flags, const RayL& ray, float t, int32_t pos, HitL& h)
 {
-    const PrimRecord* rec = sv.prims + pos;
+    const PrimRecord* rec = ((flags & F_ACCEL) ? sv.prims : sv.prims_flat) + pos;
     const int32_t prim_id = rec->prim_id;
     const uint32_t km = rec->kind_mat;
     const MaterialRec* m = sv.materials + (km & 0x7fffffffu);
