@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips",
-    "rt_rand31", "rt_profile_enable", "rt_profile_read",
+    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check",
 ]
 
 
@@ -137,6 +137,8 @@ class Library:
                                              C.c_void_p]
         c.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
         c.rt_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        c.rt_debug_div_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64)]
         c.rt_rand31.restype = C.c_uint32
         c.rt_rand31.argtypes = [C.c_uint32] * 6
 
@@ -233,6 +235,12 @@ class Library:
         self._check(self.c.rt_profile_read(bvh.handle, C.c_void_p(stream) if stream else None, C.byref(ms),
                                            C.byref(n), 1 if reset else 0))
         return ms.value, int(n.value)
+
+    def debug_div_check(self, seed: int, mode: int, n_samples: int):
+        """(mismatches, fast-path samples) of the slab test's exact division vs IEEE '/' on the device."""
+        bad, fast = C.c_uint64(), C.c_uint64()
+        self._check(self.c.rt_debug_div_check(seed, mode, n_samples, C.byref(bad), C.byref(fast)))
+        return int(bad.value), int(fast.value), (self.c.rt_last_error() or b"").decode()
 
     def rand31(self, seed, pixel, level, light, sample, dim) -> int:
         return int(self.c.rt_rand31(seed, pixel, level, light, sample, dim))

@@ -655,6 +655,29 @@ int rt_intersect_batch(const rt_bvh* cbvh, rt_ray* rays, uint32_t n_rays, const 
     return RT_OK;
 }
 
+int rt_debug_div_check(uint32_t seed, uint32_t mode, uint64_t n_samples, uint64_t* mismatches,
+    uint64_t* fast_path_samples)
+{
+    DevBuf<unsigned long long> out;
+    HIP_TRY(out.reserve(4));
+    HIP_TRY(hipMemset(out.p, 0, 4 * sizeof(unsigned long long)));
+    const uint32_t per_thread = 256;
+    const uint64_t threads = (n_samples + per_thread - 1) / per_thread;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, (threads + 255) / 256);
+    rt::launch_div_check(seed, mode, blocks, per_thread, out.p, nullptr);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (mismatches)
+        *mismatches = h[0];
+    if (fast_path_samples)
+        *fast_path_samples = h[1];
+    if (h[0])
+        g_error = "div_by_ray != n / d, first at n bits " + std::to_string((uint32_t)h[2]) + ", d bits "
+            + std::to_string((uint32_t)h[3]);
+    return RT_OK;
+}
+
 int rt_profile_enable(rt_bvh* bvh, int enable)
 {
     if (!bvh)

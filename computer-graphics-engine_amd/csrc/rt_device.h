@@ -97,8 +97,9 @@ struct LaneCounters {
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
 };
 
-// Per-wave LDS working set (8 KiB): ray table, best-key slots, the per-lane DFS
-// stacks (slot [level][lane]: conflict-free) and the (ray, leaf) pair queue.
+// Per-wave LDS working set (8.25 KiB): ray table, best-key slots, the per-lane
+// deques (slot [level][lane]: conflict-free; entry = node pair index << 6 | ray
+// slot) and the (ray, leaf) pair queue.
 constexpr uint32_t kStackLevels = 16; // MAX_DEPTH = 16 levels ⇒ at most 15 internal levels pending
 constexpr uint32_t kLeafQueue = 192;  // < 64 left over + at most 128 appended per node step
 struct alignas(16) WaveLds {
@@ -107,15 +108,56 @@ struct alignas(16) WaveLds {
     unsigned long long best[64];
     uint32_t stack[kStackLevels][64];
     uint32_t lq_ref[kLeafQueue];
-    uint32_t lq_rc[kLeafQueue]; // ray lane (6 bits) | count << 6
+    uint32_t lq_rc[kLeafQueue]; // ray slot (6 bits) | count << 6
+    uint32_t xfer[64];          // work-stealing hand-over slots
 };
-static_assert(sizeof(WaveLds) == 8192, "WaveLds");
+static_assert(sizeof(WaveLds) == 8448, "WaveLds");
 
 // ---- primitive tests (decls src/intersect.h:5-16) -----
 
+// Correctly rounded n / d from a correctly rounded reciprocal y = RN(1/d):
+//   q0 = RN(n*y);  r = n - d*q0 (exact, one FMA);  q = RN(q0 + r*y)
+// equals RN(n/d) (Markstein's theorem) as long as nothing under/overflows on the
+// way. The slab test divides TWELVE numerators by the same three ray-direction
+// components, so the reciprocals are computed once per ray (IEEE '/') and each
+// quotient costs 3 instructions instead of the ~11 of the full division sequence.
+// `ok` is the per-axis guard computed with the reciprocal (RayInv): it is false
+// for extreme |d| and for the all-ones significand that the theorem excludes;
+// extreme or zero numerators also take the plain '/' path. The FMAs here are
+// explicit — they do not change any result bit (rt_debug_div_check verifies
+// q == n / d exhaustively on the device) and -ffp-contract=off stays in force
+// for everything else.
+struct RayInv {
+    float y[3]; // RN(1 / d[a])
+    bool ok[3];
+};
+RT_DEV RayInv make_ray_inv(const RayL& r)
+{
+    RayInv v;
+    const float d[3] = { r.d.x, r.d.y, r.d.z };
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        v.y[a] = 1.0f / d[a];
+        const uint32_t b = __float_as_uint(d[a]);
+        const uint32_t e = (b >> 23) & 0xffu;
+        v.ok[a] = e >= 127u - 40u && e <= 127u + 40u && (b & 0x7fffffu) != 0x7fffffu;
+    }
+    return v;
+}
+RT_DEV float div_by_ray(float n, float d, float y, bool ok)
+{
+    const uint32_t e = (__float_as_uint(n) >> 23) & 0xffu;
+    if (ok && e >= 127u - 60u && e <= 127u + 60u) {
+        const float q0 = n * y;
+        const float r = __builtin_fmaf(-d, q0, n);
+        return __builtin_fmaf(r, y, q0);
+    }
+    return n / d;
+}
+
 // A.4 intersectRayWithShape(AxisAlignedBox) with ray.t = FLT_MAX (bvh.cpp:336,344):
 // only the boolean matters.
-RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r)
+RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const RayInv& inv)
 {
     float tl[3], th[3];
     const float o[3] = { r.o.x, r.o.y, r.o.z };
@@ -126,8 +168,8 @@ RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r)
             tl[a] = kFltMin;
             th[a] = kFltMax;
         } else {
-            tl[a] = (lo[a] - o[a]) / d[a];
-            th[a] = (hi[a] - o[a]) / d[a];
+            tl[a] = div_by_ray(lo[a] - o[a], d[a], inv.y[a], inv.ok[a]);
+            th[a] = div_by_ray(hi[a] - o[a], d[a], inv.y[a], inv.ok[a]);
         }
     }
     float tin = sel_max(sel_min(th[2], tl[2]), sel_max(sel_min(th[1], tl[1]), sel_min(th[0], tl[0])));
@@ -222,7 +264,61 @@ RT_DEV uint32_t key_index(unsigned long long key)
 
 // ---- leaf phase -----------------------------------------------------------------
 // Entries [first, first + n) of the wave's leaf queue, n <= 64: two entries per
-// step, one per half-wave, one primitive per lane.
+// step, one per half-wave, one primitive per lane. The record fetch of step k+1
+// is issued before step k is tested (software pipeline: the loop is otherwise a
+// chain of dependent ~1 µs gathers).
+struct LeafSlot {
+    PrimRecord rec;
+    uint32_t r, ref, cnt, cmax; // ray slot, first primitive, this half's count, max of both halves
+    bool live;                  // this lane holds a record of the first 32 primitives
+};
+
+template <bool ANY>
+RT_DEV void leaf_fetch(const WaveLds& L, const PrimRecord* __restrict__ prims, uint32_t my_ref, uint32_t my_rc,
+    uint32_t k, uint32_t n, bool upper, uint32_t sub, LeafSlot& s)
+{
+    const uint32_t ref0 = read_lane(my_ref, k), rc0 = read_lane(my_rc, k);
+    const uint32_t k1 = k + 1 < n ? k + 1 : k;
+    const uint32_t ref1 = read_lane(my_ref, k1), rc1 = (k + 1 < n) ? read_lane(my_rc, k1) : 0u;
+    s.ref = upper ? ref1 : ref0;
+    const uint32_t rc = upper ? rc1 : rc0;
+    s.r = rc & 63u;
+    s.cnt = rc >> 6;
+    const uint32_t c0 = rc0 >> 6, c1 = rc1 >> 6;
+    s.cmax = c0 > c1 ? c0 : c1;
+    s.live = sub < s.cnt;
+    if (ANY && s.live && L.best[s.r] != kNoHit)
+        s.live = false; // this shadow ray is already blocked
+    if (s.live)
+        s.rec = prims[s.ref + sub];
+}
+
+template <bool COUNT>
+RT_DEV void leaf_test_one(WaveLds& L, const PrimRecord& rec, uint32_t r, uint32_t index, LaneCounters& lc)
+{
+    const float4 a = L.rayA[r], b = L.rayB[r];
+    RayL ray;
+    ray.o = mk(a.x, a.y, a.z);
+    ray.d = mk(a.w, b.x, b.y);
+    const float t0 = b.z;
+    float tt;
+    bool cand;
+    const bool sphere = (rec.kind_mat & 0x80000000u) != 0u;
+    if (!sphere) {
+        cand = tri_candidate(rec, ray, t0, tt);
+        if (COUNT)
+            lc.tri++;
+    } else {
+        cand = sphere_candidate(rec, ray, t0, tt);
+        if (COUNT)
+            lc.sph++;
+    }
+    if (COUNT)
+        lc.tri_fetch++;
+    if (cand)
+        atomicMin(&L.best[r], make_key(tt, index, sphere));
+}
+
 template <bool ANY, bool COUNT>
 RT_DEV void leaf_phase(WaveLds& L, const PrimRecord* __restrict__ prims, uint32_t first, uint32_t n, uint32_t lane,
     LaneCounters& lc)
@@ -234,44 +330,24 @@ RT_DEV void leaf_phase(WaveLds& L, const PrimRecord* __restrict__ prims, uint32_
     }
     const bool upper = lane >= 32u;
     const uint32_t sub = lane & 31u;
+    LeafSlot cur, nxt;
+    leaf_fetch<ANY>(L, prims, my_ref, my_rc, 0u, n, upper, sub, cur);
     for (uint32_t k = 0; k < n; k += 2) {
-        const uint32_t ref0 = read_lane(my_ref, k), rc0 = read_lane(my_rc, k);
-        const uint32_t ref1 = read_lane(my_ref, k + 1), rc1 = (k + 1 < n) ? read_lane(my_rc, k + 1) : 0u;
-        const uint32_t ref = upper ? ref1 : ref0;
-        const uint32_t rc = upper ? rc1 : rc0;
-        const uint32_t r = rc & 63u, cnt = rc >> 6;
-        const uint32_t c0 = rc0 >> 6, c1 = rc1 >> 6;
-        const uint32_t cmax = c0 > c1 ? c0 : c1;
-        for (uint32_t base = 0; base < cmax; base += 32u) {
+        nxt.live = false;
+        nxt.cmax = 0;
+        if (k + 2 < n)
+            leaf_fetch<ANY>(L, prims, my_ref, my_rc, k + 2, n, upper, sub, nxt);
+        if (cur.live)
+            leaf_test_one<COUNT>(L, cur.rec, cur.r, cur.ref + sub, lc);
+        // leaves larger than 32 primitives (brute-force mode, very large meshes)
+        for (uint32_t base = 32u; base < cur.cmax; base += 32u) {
             const uint32_t idx = base + sub;
-            if (idx < cnt) {
-                if (ANY && L.best[r] != kNoHit)
-                    continue; // this shadow ray is already blocked
-                const float4 a = L.rayA[r], b = L.rayB[r];
-                RayL ray;
-                ray.o = mk(a.x, a.y, a.z);
-                ray.d = mk(a.w, b.x, b.y);
-                const float t0 = b.z;
-                const uint32_t index = ref + idx;
-                const PrimRecord rec = prims[index];
-                float tt;
-                bool cand;
-                const bool sphere = (rec.kind_mat & 0x80000000u) != 0u;
-                if (!sphere) {
-                    cand = tri_candidate(rec, ray, t0, tt);
-                    if (COUNT)
-                        lc.tri++;
-                } else {
-                    cand = sphere_candidate(rec, ray, t0, tt);
-                    if (COUNT)
-                        lc.sph++;
-                }
-                if (COUNT)
-                    lc.tri_fetch++;
-                if (cand)
-                    atomicMin(&L.best[r], make_key(tt, index, sphere));
+            if (idx < cur.cnt && !(ANY && L.best[cur.r] != kNoHit)) {
+                const PrimRecord rec = prims[cur.ref + idx];
+                leaf_test_one<COUNT>(L, rec, cur.r, cur.ref + idx, lc);
             }
         }
+        cur = nxt;
     }
 }
 
@@ -284,6 +360,14 @@ RT_DEV void leaf_phase(WaveLds& L, const PrimRecord* __restrict__ prims, uint32_
 // `active` selects the lanes that carry a ray; ALL lanes of the wave must call.
 // use_bvh = features.enableAccelStructure; when false the whole array is one leaf
 // in the reference's own order (bvh.cpp:303-305; sv.prims_flat).
+//
+// Node phase = depth-first walk with WORK STEALING inside the wave: every lane is
+// a worker with a private deque of (ray slot, node) entries in LDS; a lane whose
+// deque is empty takes the OLDEST entry (the largest pending subtree) of a lane
+// that holds at least two. Because the closest-hit reduction is order-free, any
+// lane may walk any part of any ray's tree; lanes that carry no ray of their own
+// (sparse reflection levels, finished rays) pick up work immediately, so a wave's
+// time is its total work / 64 rather than its longest ray.
 template <bool ANY, bool COUNT>
 RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool active, const RayL& ray, float& t, int32_t& pos,
     LaneCounters& lc, WaveLds& L)
@@ -297,8 +381,11 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool active, const RayL&
     L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t, 0.0f);
     L.best[lane] = kNoHit;
 
-    uint32_t sp = 0;   // this lane's stack depth
-    uint32_t lq_n = 0; // leaf-queue fill (wave-uniform)
+    uint32_t bot = 0, sp = 0; // this lane's deque = stack[bot .. sp)
+    uint32_t lq_n = 0;        // leaf-queue fill (wave-uniform)
+    RayL cur = ray;           // ray of the entry being processed (cached in registers)
+    RayInv cur_inv = make_ray_inv(cur);
+    uint32_t cur_r = lane;
     const bool root_is_leaf = !use_bvh || sv.root_cnt != 0u;
     if (root_is_leaf) {
         const uint64_t m = ballot(active);
@@ -309,54 +396,99 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool active, const RayL&
         }
         lq_n = (uint32_t)__builtin_popcountll(m);
     } else if (active) {
-        L.stack[0][lane] = sv.root_ref; // the root's own box is never tested (bvh.cpp:313)
+        L.stack[0][lane] = (sv.root_ref << 6) | lane; // the root's own box is never tested (bvh.cpp:313)
         sp = 1;
     }
     wave_lds_fence();
 
-    while (ballot(sp > 0) != 0) {
-        // ---- node phase: every lane with work pops one internal node of ITS ray ----
+    for (;;) {
+        const uint64_t busy = ballot(sp > bot);
+        if (busy == 0)
+            break;
+        // ---- steal: idle lanes take the oldest entry of lanes holding >= 2 ----------
+        if (busy != ~0ull) {
+            const bool donor = sp - bot >= 2u;
+            const uint64_t donors = ballot(donor);
+            if (donors) {
+                const uint64_t idle = ~busy;
+                const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+                const uint32_t n_don = (uint32_t)__builtin_popcountll(donors);
+                const uint32_t n_x = n_idle < n_don ? n_idle : n_don;
+                const bool is_idle = sp == bot;
+                if (donor) {
+                    const uint32_t k = prefix_count(donors);
+                    if (k < n_x) {
+                        L.xfer[k] = L.stack[bot][lane];
+                        bot++;
+                    }
+                }
+                wave_lds_fence();
+                if (is_idle) {
+                    const uint32_t k = prefix_count(idle);
+                    if (k < n_x) {
+                        L.stack[0][lane] = L.xfer[k];
+                        bot = 0;
+                        sp = 1;
+                    }
+                }
+                wave_lds_fence();
+            }
+        }
+        // ---- node phase: every lane with work pops one internal node ---------------
         bool leaf_l = false, leaf_r = false;
-        uint32_t l_ref = 0, l_cnt = 0, r_ref = 0, r_cnt = 0;
-        if (sp > 0) {
+        uint32_t l_ref = 0, l_cnt = 0, r_ref = 0, r_cnt = 0, r = 0;
+        if (sp > bot) {
             sp--;
-            const NodePair* np = sv.nodes + L.stack[sp][lane];
-            const float4 q0 = *reinterpret_cast<const float4*>(&np->l_lo[0]); // l_lo xyz, l_hi x
-            const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
-            const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
-            const uint4 q3 = *reinterpret_cast<const uint4*>(&np->l_ref);
-            const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
-            const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
-            const bool hl = box_hit(llo, lhi, ray);
-            const bool hr = box_hit(rlo, rhi, ray);
-            l_ref = q3.x, l_cnt = q3.y, r_ref = q3.z, r_cnt = q3.w;
-            if (COUNT) {
-                lc.box += 2;
-                lc.node_fetch++;
+            const uint32_t e = L.stack[sp][lane];
+            if (sp == bot)
+                sp = bot = 0;
+            r = e & 63u;
+            if (!(ANY && L.best[r] != kNoHit)) { // a blocked shadow ray needs no more tests
+                if (r != cur_r) {
+                    const float4 a = L.rayA[r], b = L.rayB[r];
+                    cur.o = mk(a.x, a.y, a.z);
+                    cur.d = mk(a.w, b.x, b.y);
+                    cur_inv = make_ray_inv(cur);
+                    cur_r = r;
+                }
+                const NodePair* np = sv.nodes + (e >> 6);
+                const float4 q0 = *reinterpret_cast<const float4*>(&np->l_lo[0]); // l_lo xyz, l_hi x
+                const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
+                const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
+                const uint4 q3 = *reinterpret_cast<const uint4*>(&np->l_ref);
+                const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
+                const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
+                const bool hl = box_hit(llo, lhi, cur, cur_inv);
+                const bool hr = box_hit(rlo, rhi, cur, cur_inv);
+                l_ref = q3.x, l_cnt = q3.y, r_ref = q3.z, r_cnt = q3.w;
+                if (COUNT) {
+                    lc.box += 2;
+                    lc.node_fetch++;
+                }
+                if (hl && l_cnt == 0u) {
+                    L.stack[sp][lane] = (l_ref << 6) | r;
+                    sp++;
+                }
+                if (hr && r_cnt == 0u) {
+                    L.stack[sp][lane] = (r_ref << 6) | r;
+                    sp++;
+                }
+                leaf_l = hl && l_cnt != 0u;
+                leaf_r = hr && r_cnt != 0u;
             }
-            if (hl && l_cnt == 0u) {
-                L.stack[sp][lane] = l_ref;
-                sp++;
-            }
-            if (hr && r_cnt == 0u) {
-                L.stack[sp][lane] = r_ref;
-                sp++;
-            }
-            leaf_l = hl && l_cnt != 0u;
-            leaf_r = hr && r_cnt != 0u;
         }
         const uint64_t ml = ballot(leaf_l), mr = ballot(leaf_r);
         if (ml | mr) {
             if (leaf_l) {
                 const uint32_t o = lq_n + prefix_count(ml);
                 L.lq_ref[o] = l_ref;
-                L.lq_rc[o] = lane | (l_cnt << 6);
+                L.lq_rc[o] = r | (l_cnt << 6);
             }
             lq_n += (uint32_t)__builtin_popcountll(ml);
             if (leaf_r) {
                 const uint32_t o = lq_n + prefix_count(mr);
                 L.lq_ref[o] = r_ref;
-                L.lq_rc[o] = lane | (r_cnt << 6);
+                L.lq_rc[o] = r | (r_cnt << 6);
             }
             lq_n += (uint32_t)__builtin_popcountll(mr);
             if (lq_n >= 64u) {
@@ -366,8 +498,6 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool active, const RayL&
                     leaf_phase<ANY, COUNT>(L, prims, lq_n, 64u, lane, lc);
                 } while (lq_n >= 64u);
                 wave_lds_fence();
-                if (ANY && L.best[lane] != kNoHit)
-                    sp = 0; // blocked: drop the rest of this ray's tree
             }
         }
     }

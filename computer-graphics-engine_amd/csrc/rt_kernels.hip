@@ -24,7 +24,9 @@ namespace rt {
 
 namespace {
 
-constexpr int kBlock = 256; // 4 waves, one 8x8 pixel tile (or 64 queued rays) each
+constexpr int kBlock = 256; // 4 waves, one 8x8 pixel tile (or up to 64 queued rays) each
+constexpr uint32_t kMinWaves = 4096;      // aim for >= 4 busy waves per SIMD on sparse levels
+constexpr uint32_t kMinRaysPerWave = 4;
 
 RT_DEV V3 quat_rotate(const float* q, V3 v)
 {
@@ -78,6 +80,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
     const uint32_t box = wave_sum(lc.box), tri = wave_sum(lc.tri), sph = wave_sum(lc.sph);
     const uint32_t closest = wave_sum(rc.closest), shadow = wave_sum(rc.shadow);
     const uint32_t hits = wave_sum(rc.hits), queued = wave_sum(rc.queued);
+    const uint32_t node_fetch = wave_sum(lc.node_fetch), tri_fetch = wave_sum(lc.tri_fetch);
     if (lane == 0) {
         auto add = [](uint64_t* p, uint64_t v) {
             if (v)
@@ -90,8 +93,8 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
         add(&out->box_tests, box);
         add(&out->tri_tests, tri);
         add(&out->sphere_tests, sph);
-        add(&out->node_fetches, lc.node_fetch);
-        add(&out->tri_fetches, lc.tri_fetch);
+        add(&out->node_fetches, node_fetch);
+        add(&out->tri_fetches, tri_fetch);
         add(&out->hits_shaded, hits);
         add(&out->rays_queued, queued);
     }
@@ -122,8 +125,18 @@ __global__ __launch_bounds__(kBlock) void k_trace_level(const LevelArgs a)
         }
     } else {
         const uint32_t count = a.source == SRC_QUEUE ? *a.in_count : a.in_count_imm;
-        const uint32_t i = wave * 64u + lane;
-        active = i < count;
+        // Sparse levels: give each wave only R < 64 rays, so that the wave's other
+        // lanes start idle and share those rays' trees by work stealing (rt_device.h).
+        // R is the largest power of two that still leaves >= kMinWaves busy waves,
+        // raised again if the grid would not cover the queue.
+        const uint32_t n_waves = gridDim.x * (kBlock / 64);
+        uint32_t R = 64u;
+        while (R > kMinRaysPerWave && (count + R - 1u) / R < kMinWaves)
+            R >>= 1;
+        while ((uint64_t)R * n_waves < count)
+            R <<= 1;
+        const uint32_t i = wave * R + lane;
+        active = lane < R && i < count;
         if (active) {
             const float* q = a.in.ray;
             const size_t cap = a.in.cap;
@@ -392,6 +405,57 @@ __global__ __launch_bounds__(256) void k_deinterleave(const float* __restrict__ 
     dst[0] = src[0], dst[1] = src[1], dst[2] = src[2];
 }
 
+// rt_debug_div_check: div_by_ray(n, d, RN(1/d)) against the device's own n / d on
+// pseudo-random operands. mode 0: raw random bit patterns (extremes, NaN/inf →
+// guard paths); 1: moderate exponents (the fast path); 2: d with an all-ones
+// significand; 3: slab-test shaped operands (n = bound - origin with cancellation).
+__global__ __launch_bounds__(256) void k_div_check(uint32_t seed, uint32_t mode, uint32_t per_thread,
+    unsigned long long* out /* [0] mismatches, [1] fast-path count, [2],[3] first mismatching n, d bits */)
+{
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    uint32_t h = pcg_hash(seed ^ (tid * 0x9E3779B9u));
+    unsigned long long bad = 0, fast = 0;
+    for (uint32_t i = 0; i < per_thread; i++) {
+        h = pcg_hash(h + i);
+        uint32_t nb = h;
+        h = pcg_hash(h ^ 0x85ebca6bu);
+        uint32_t db = h;
+        if (mode == 1u) { // exponents in [2^-20, 2^20)
+            nb = (nb & 0x807fffffu) | ((107u + (nb >> 23) % 40u) << 23);
+            db = (db & 0x807fffffu) | ((107u + (db >> 23) % 40u) << 23);
+        } else if (mode == 2u) {
+            nb = (nb & 0x807fffffu) | ((107u + (nb >> 23) % 40u) << 23);
+            db = (db & 0x80000000u) | ((107u + (db >> 23) % 40u) << 23) | 0x7fffffu;
+        }
+        float n = __uint_as_float(nb), d = __uint_as_float(db);
+        if (mode == 3u) {
+            const float o = (float)(int32_t)(nb & 0xffffu) / 4096.0f - 8.0f;
+            const float b = o + (float)(int32_t)((nb >> 16) & 0xffu) * __uint_as_float(0x33800000u + ((db & 7u) << 23));
+            n = b - o;
+            d = __uint_as_float((db & 0x807fffffu) | ((100u + (db >> 23) % 28u) << 23));
+        }
+        if (d == 0.0f)
+            continue;
+        RayL r;
+        r.o = mk(0, 0, 0), r.d = mk(d, d, d);
+        const RayInv inv = make_ray_inv(r);
+        const float q = div_by_ray(n, d, inv.y[0], inv.ok[0]);
+        const float ref = n / d;
+        const uint32_t ne = (__float_as_uint(n) >> 23) & 0xffu;
+        if (inv.ok[0] && ne >= 127u - 60u && ne <= 127u + 60u)
+            fast++;
+        const bool same = __float_as_uint(q) == __float_as_uint(ref) || (q != q && ref != ref);
+        if (!same) {
+            if (bad == 0 && atomicCAS(&out[2], 0ull, (unsigned long long)__float_as_uint(n) | 1ull << 63) == 0ull)
+                out[3] = __float_as_uint(d);
+            bad++;
+        }
+    }
+    if (bad)
+        atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], fast);
+}
+
 uint32_t grid_for_waves(uint64_t waves) { return (uint32_t)((waves + (kBlock / 64) - 1) / (kBlock / 64)); }
 
 uint64_t camera_waves(const CameraArgs& c)
@@ -436,6 +500,12 @@ void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s)
         hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+void launch_div_check(uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t per_thread, unsigned long long* out,
+    hipStream_t s)
+{
+    hipLaunchKernelGGL(k_div_check, dim3(blocks), dim3(256), 0, s, seed, mode, per_thread, out);
 }
 
 void launch_deinterleave(const float* gathered, float* frame, int32_t width, int32_t height, int32_t strip_rows,

@@ -264,6 +264,15 @@ int rt_profile_enable(rt_bvh* bvh, int enable);
 int rt_profile_read(rt_bvh* bvh, void* hip_stream, double* trace_kernel_ms, uint64_t* trace_kernel_launches,
                     int reset);
 
+/* -- Device self-check of the slab test's reciprocal-based exact division
+ *    (csrc/rt_device.h div_by_ray) against the device's own IEEE '/', on
+ *    n_samples pseudo-random operand pairs. mode: 0 raw bit patterns, 1 moderate
+ *    exponents, 2 divisors with an all-ones significand, 3 slab-shaped operands.
+ *    Returns the number of differing quotients (must be 0) and how many samples
+ *    took the fast path. ------------------------------------------------------- */
+int rt_debug_div_check(uint32_t seed, uint32_t mode, uint64_t n_samples, uint64_t* mismatches,
+                       uint64_t* fast_path_samples);
+
 /* -- Multi-GPU strip de-interleave: gathered packed strips
  *    of all ranks → the reference's row-flipped frame. gathered_dev holds
  *    n_ranks blocks of rows_per_rank_max*W*3 floats; strip s (strip_rows image
