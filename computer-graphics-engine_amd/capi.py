@@ -8,6 +8,7 @@ compute calls raise `RtError` (RT_ERR_DEVICE).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 from typing import Optional, Sequence
@@ -24,7 +25,7 @@ EXPORTS = [
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips",
-    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check",
+    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check", "rt_set_option",
 ]
 
 
@@ -99,6 +100,8 @@ class Bvh:
 class Library:
     def __init__(self, build: bool = True):
         path = build_library() if build else LIB_PATH
+        if os.environ.get("RT_WHITTED_LIB"):  # diagnostic builds (e.g. -DRT_STAMPS), tools/ only
+            path = Path(os.environ["RT_WHITTED_LIB"])
         # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.
         # Importing torch first makes the loader bind this library's NEEDED
         # libamdhip64.so.7 to the copy torch already mapped, so device pointers and
@@ -137,6 +140,7 @@ class Library:
                                              C.c_void_p]
         c.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
         c.rt_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        c.rt_set_option.argtypes = [C.c_char_p, C.c_int]
         c.rt_debug_div_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]
         c.rt_rand31.restype = C.c_uint32
@@ -152,6 +156,9 @@ class Library:
         buf = C.create_string_buffer(256)
         self._check(self.c.rt_device_info(C.byref(n), buf, 256))
         return n.value, buf.value.decode()
+
+    def set_option(self, name: str, value: int):
+        self._check(self.c.rt_set_option(name.encode(), int(value)))
 
     def set_device(self, device: int):
         self._check(self.c.rt_set_device(device))

@@ -206,6 +206,11 @@ std::string HostScene::load(const rt_scene_desc& d)
             any_non_opaque = true;
         materials.push_back(mr);
     }
+    for (float v : positions)
+        extent = std::max(extent, std::fabs(v));
+    for (const rt_sphere_desc& sp : spheres)
+        for (int a = 0; a < 3; a++)
+            extent = std::max(extent, std::fabs(sp.center[a]) + std::fabs(sp.radius));
     return convert_lights(d.lights, d.n_lights, lights);
 }
 

@@ -30,6 +30,7 @@ struct HostScene {
     std::vector<float> texels;
     std::vector<LightRec> lights;
     uint32_t n_triangles = 0;
+    float extent = 0.0f;         // largest |coordinate| of any vertex / sphere bound
     bool any_non_opaque = false; // some material.transparency != 1 (src/render.cpp:122)
 
     // returns "" on success, otherwise what is wrong with the descriptor

@@ -7,6 +7,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -24,6 +25,11 @@ namespace {
 thread_local std::string g_error;
 // host-output entry points share the default-stream scratch of a bvh: one at a time
 std::mutex g_host_call_mu;
+// rt_set_option("unpruned", 1): traverse with the reference's own policy (no pruning)
+std::atomic<int> g_unpruned { 0 };
+// rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
+std::atomic<int> g_leaf_flush { 16 };
+unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
 {
@@ -135,6 +141,8 @@ struct rt_bvh {
         v.nodes = nodes.p;
         v.prims = prims.p;
         v.prims_flat = prims_flat.p;
+        v.chunks = reinterpret_cast<const float4*>(prims.p);
+        v.chunks_flat = reinterpret_cast<const float4*>(prims_flat.p);
         v.tri_vidx = scene->tri_vidx.p;
         v.vnormal = scene->vnormal.p;
         v.vtexcoord = scene->vtexcoord.p;
@@ -146,6 +154,10 @@ struct rt_bvh {
         v.root_ref = host.root_ref;
         v.root_cnt = host.root_cnt;
         v.n_prims = (uint32_t)host.records.size();
+        v.prune_ok = scene->host.spheres.empty() ? 1u : 0u;
+        v.extent = scene->host.extent;
+        v.leaf_flush = (uint32_t)g_leaf_flush.load();
+        v.stamps = g_stamps;
         return v;
     }
 };
@@ -163,6 +175,7 @@ uint32_t feature_flags(const rt_features& f)
     if (f.enableTextureMapping) fl |= rt::F_TEXTURE;
     if (f.enableAccelStructure) fl |= rt::F_ACCEL;
     if (f.enableBilinearTextureFiltering) fl |= rt::F_BILINEAR;
+    if (g_unpruned.load()) fl |= rt::F_NO_PRUNE;
     return fl;
 }
 
@@ -332,6 +345,21 @@ int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len)
         snprintf(name_buf, name_buf_len, "%s (%s)", prop.name, prop.gcnArchName);
     }
     return RT_OK;
+}
+
+int rt_set_option(const char* name, int value)
+{
+    if (name && strcmp(name, "unpruned") == 0) {
+        g_unpruned.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "leaf_flush") == 0) {
+        if (value < 1 || value > 64)
+            return fail(RT_ERR_INVALID, "rt_set_option: leaf_flush must be in [1, 64]");
+        g_leaf_flush.store(value);
+        return RT_OK;
+    }
+    return fail(RT_ERR_INVALID, std::string("rt_set_option: unknown option ") + (name ? name : "(null)"));
 }
 
 int rt_set_device(int device)
@@ -675,6 +703,19 @@ int rt_debug_div_check(uint32_t seed, uint32_t mode, uint64_t n_samples, uint64_
     if (h[0])
         g_error = "div_by_ray != n / d, first at n bits " + std::to_string((uint32_t)h[2]) + ", d bits "
             + std::to_string((uint32_t)h[3]);
+    return RT_OK;
+}
+
+// Diagnostic (library built with -DRT_STAMPS): zero / read the 16 phase-clock slots.
+int rt_debug_stamps(int reset, unsigned long long* out16)
+{
+    if (!g_stamps)
+        HIP_TRY(hipMalloc((void**)&g_stamps, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipDeviceSynchronize());
+    if (out16)
+        HIP_TRY(hipMemcpy(out16, g_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset)
+        HIP_TRY(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
     return RT_OK;
 }
 

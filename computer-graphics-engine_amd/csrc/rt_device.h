@@ -20,14 +20,11 @@
 // Hence closest-hit = min over candidates of the key (t, tie rank) — a reduction
 // that is independent of evaluation order. The host stores primitives in the
 // reference's visit order (rt_layout.h), so "later in the fixed order" is simply
-// "larger array index", and the kernel is free to:
-//   - walk each ray's tree depth-first with a per-lane stack in LDS (node phase),
-//   - park every (ray, leaf) pair it finds in a per-wave LDS queue, and
-//   - test leaves in a separate phase where HALF A WAVE works on ONE pair, one
-//     triangle per lane: consecutive lanes read consecutive 96-byte records
-//     (coalesced), the ray is an LDS broadcast, and a candidate lane publishes
-//     its key with one 64-bit LDS atomic-min. Shadow rays (any-hit) stop as soon
-//     as their slot holds a key.
+// "larger array index", and the traversal (rt_traverse.h) is free to walk the
+// tree in any order, to split one ray's tree over several lanes, and to test
+// leaves in a separate phase; a candidate publishes its key with one 64-bit LDS
+// atomic-min into its ray's slot. Shadow rays (any-hit) stop as soon as their
+// slot holds a key.
 //
 // Arithmetic: every float op is a separately rounded IEEE binary32 op in the
 // reference's order (file built with -ffp-contract=off; '/' and sqrtf are
@@ -92,14 +89,25 @@ RT_DEV void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Diagnostic build only (-DRT_STAMPS): per-phase shader-clock sums of lane 0 of
+// every wave, written to SceneView::stamps (never to an output). Not compiled
+// into the shipped library.
+#ifdef RT_STAMPS
+#define RT_STAMP(var) const unsigned long long var = clock64()
+#define RT_STAMP_ADD(slot, a, b) stamp_acc[slot] += (b) - (a), stamp_n[slot]++
+#else
+#define RT_STAMP(var)
+#define RT_STAMP_ADD(slot, a, b)
+#endif
+
 struct LaneCounters {
     uint32_t box = 0, tri = 0, sph = 0;     // lane-level tests
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
 };
 
-// Per-wave LDS working set (8.25 KiB): ray table, best-key slots, the per-lane
+// Per-wave LDS working set (13.5 KiB): ray table, best-key slots, the per-lane
 // deques (slot [level][lane]: conflict-free; entry = node pair index << 6 | ray
-// slot) and the (ray, leaf) pair queue.
+// slot, plus the entry's distance lower bound) and the (ray, leaf) pair queue.
 constexpr uint32_t kStackLevels = 16; // MAX_DEPTH = 16 levels ⇒ at most 15 internal levels pending
 constexpr uint32_t kLeafQueue = 192;  // < 64 left over + at most 128 appended per node step
 struct alignas(16) WaveLds {
@@ -107,11 +115,14 @@ struct alignas(16) WaveLds {
     float4 rayB[64]; // dy dz t0 -
     unsigned long long best[64];
     uint32_t stack[kStackLevels][64];
+    float stack_lb[kStackLevels][64];
     uint32_t lq_ref[kLeafQueue];
     uint32_t lq_rc[kLeafQueue]; // ray slot (6 bits) | count << 6
+    float lq_lb[kLeafQueue];
     uint32_t xfer[64];          // work-stealing hand-over slots
+    float xfer_lb[64];
 };
-static_assert(sizeof(WaveLds) == 8448, "WaveLds");
+static_assert(sizeof(WaveLds) == 13568, "WaveLds");
 
 // ---- primitive tests (decls src/intersect.h:5-16) -----
 
@@ -130,18 +141,26 @@ static_assert(sizeof(WaveLds) == 8448, "WaveLds");
 struct RayInv {
     float y[3]; // RN(1 / d[a])
     bool ok[3];
+    float slack; // rho * max_a |1/d[a]|: how far a slab plane moved by rho shifts t (pruning bound)
 };
-RT_DEV RayInv make_ray_inv(const RayL& r)
+// `extent` = largest |coordinate| of the scene (SceneView::extent).
+RT_DEV RayInv make_ray_inv(const RayL& r, float extent)
 {
     RayInv v;
     const float d[3] = { r.d.x, r.d.y, r.d.z };
+    float ymax = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         v.y[a] = 1.0f / d[a];
         const uint32_t b = __float_as_uint(d[a]);
         const uint32_t e = (b >> 23) & 0xffu;
         v.ok[a] = e >= 127u - 40u && e <= 127u + 40u && (b & 0x7fffffu) != 0x7fffffu;
+        if (d[a] != 0.0f)
+            ymax = fmaxf(ymax, fabsf(v.y[a]));
     }
+    // rho (see "Pruning" below): 2^-16 of the largest coordinate magnitude in play
+    const float S = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fmaxf(fabsf(r.o.z), extent));
+    v.slack = (S * 1.52587890625e-05f) * ymax;
     return v;
 }
 RT_DEV float div_by_ray(float n, float d, float y, bool ok)
@@ -156,8 +175,24 @@ RT_DEV float div_by_ray(float n, float d, float y, bool ok)
 }
 
 // A.4 intersectRayWithShape(AxisAlignedBox) with ray.t = FLT_MAX (bvh.cpp:336,344):
-// only the boolean matters.
-RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const RayInv& inv)
+// only the boolean matters for the reference's visit set. `lb` is the pruning
+// lower bound derived from the same slab quotients (see "Pruning").
+//
+// Pruning. The reference visits every leaf whose ancestors' boxes pass this test
+// and keeps the candidate with the smallest t. A subtree can be skipped without
+// changing that result when no primitive in it can be a candidate with
+// t <= limit (limit = min(initial ray.t, best t so far); the comparison is strict,
+// so equal-t ties are never cut). For a triangle T inside box B, a candidate's
+// point p = fl(d*t + o) passed the three edge tests and t = fl(num/den): p lies
+// within a few ulps of the scene scale S of T (relative rounding of num/den keeps
+// o + d*t within c*u*S of T's plane, the edge tests pin its in-plane position to
+// within 4u*|p - v| of T), hence inside B grown by rho = 2^-16 * S on every side —
+// 2^8 times the worst rounding bound. So t >= the ray's exact entry distance into
+// B grown by rho >= tin * (1 - 2^-20) - rho * max|1/d| =: lb, with tin the TRUE entry
+// distance computed below (before the reference's "origin inside" rewrite).
+// Spheres are excluded (their test assumes |d| = 1): scenes with spheres do not
+// prune. Proven against the unpruned traversal in tests/test_gpu_parity.py.
+RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const RayInv& inv, float& lb)
 {
     float tl[3], th[3];
     const float o[3] = { r.o.x, r.o.y, r.o.z };
@@ -174,6 +209,7 @@ RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const R
     }
     float tin = sel_max(sel_min(th[2], tl[2]), sel_max(sel_min(th[1], tl[1]), sel_min(th[0], tl[0])));
     float tout = sel_min(sel_max(th[2], tl[2]), sel_min(sel_max(th[1], tl[1]), sel_max(th[0], tl[0])));
+    lb = tin * 0.99999904632568359375f - inv.slack; // (1 - 2^-20); negative or NaN never prunes
     if (tin < 0.0f) {
         if (!(tout > 0.0f))
             return false;
@@ -262,264 +298,15 @@ RT_DEV uint32_t key_index(unsigned long long key)
     return (low & 0x80000000u) ? (low & 0x7fffffffu) : (0x7fffffffu - low);
 }
 
-// ---- leaf phase -----------------------------------------------------------------
-// Entries [first, first + n) of the wave's leaf queue, n <= 64: two entries per
-// step, one per half-wave, one primitive per lane. The record fetch of step k+1
-// is issued before step k is tested (software pipeline: the loop is otherwise a
-// chain of dependent ~1 µs gathers).
-struct LeafSlot {
-    PrimRecord rec;
-    uint32_t r, ref, cnt, cmax; // ray slot, first primitive, this half's count, max of both halves
-    bool live;                  // this lane holds a record of the first 32 primitives
-};
 
-template <bool ANY>
-RT_DEV void leaf_fetch(const WaveLds& L, const PrimRecord* __restrict__ prims, uint32_t my_ref, uint32_t my_rc,
-    uint32_t k, uint32_t n, bool upper, uint32_t sub, LeafSlot& s)
+// limit of ray slot r for pruning: min(initial ray.t, best t so far) — both are
+// >= 0, so the unsigned order of their bit patterns is their float order, and the
+// empty slot (all ones) never wins. A negative / NaN initial t has no candidates.
+RT_DEV float ray_limit(const WaveLds& L, uint32_t r)
 {
-    const uint32_t ref0 = read_lane(my_ref, k), rc0 = read_lane(my_rc, k);
-    const uint32_t k1 = k + 1 < n ? k + 1 : k;
-    const uint32_t ref1 = read_lane(my_ref, k1), rc1 = (k + 1 < n) ? read_lane(my_rc, k1) : 0u;
-    s.ref = upper ? ref1 : ref0;
-    const uint32_t rc = upper ? rc1 : rc0;
-    s.r = rc & 63u;
-    s.cnt = rc >> 6;
-    const uint32_t c0 = rc0 >> 6, c1 = rc1 >> 6;
-    s.cmax = c0 > c1 ? c0 : c1;
-    s.live = sub < s.cnt;
-    if (ANY && s.live && L.best[s.r] != kNoHit)
-        s.live = false; // this shadow ray is already blocked
-    if (s.live)
-        s.rec = prims[s.ref + sub];
-}
-
-template <bool COUNT>
-RT_DEV void leaf_test_one(WaveLds& L, const PrimRecord& rec, uint32_t r, uint32_t index, LaneCounters& lc)
-{
-    const float4 a = L.rayA[r], b = L.rayB[r];
-    RayL ray;
-    ray.o = mk(a.x, a.y, a.z);
-    ray.d = mk(a.w, b.x, b.y);
-    const float t0 = b.z;
-    float tt;
-    bool cand;
-    const bool sphere = (rec.kind_mat & 0x80000000u) != 0u;
-    if (!sphere) {
-        cand = tri_candidate(rec, ray, t0, tt);
-        if (COUNT)
-            lc.tri++;
-    } else {
-        cand = sphere_candidate(rec, ray, t0, tt);
-        if (COUNT)
-            lc.sph++;
-    }
-    if (COUNT)
-        lc.tri_fetch++;
-    if (cand)
-        atomicMin(&L.best[r], make_key(tt, index, sphere));
-}
-
-template <bool ANY, bool COUNT>
-RT_DEV void leaf_phase(WaveLds& L, const PrimRecord* __restrict__ prims, uint32_t first, uint32_t n, uint32_t lane,
-    LaneCounters& lc)
-{
-    uint32_t my_ref = 0, my_rc = 0;
-    if (lane < n) {
-        my_ref = L.lq_ref[first + lane];
-        my_rc = L.lq_rc[first + lane];
-    }
-    const bool upper = lane >= 32u;
-    const uint32_t sub = lane & 31u;
-    LeafSlot cur, nxt;
-    leaf_fetch<ANY>(L, prims, my_ref, my_rc, 0u, n, upper, sub, cur);
-    for (uint32_t k = 0; k < n; k += 2) {
-        nxt.live = false;
-        nxt.cmax = 0;
-        if (k + 2 < n)
-            leaf_fetch<ANY>(L, prims, my_ref, my_rc, k + 2, n, upper, sub, nxt);
-        if (cur.live)
-            leaf_test_one<COUNT>(L, cur.rec, cur.r, cur.ref + sub, lc);
-        // leaves larger than 32 primitives (brute-force mode, very large meshes)
-        for (uint32_t base = 32u; base < cur.cmax; base += 32u) {
-            const uint32_t idx = base + sub;
-            if (idx < cur.cnt && !(ANY && L.best[cur.r] != kNoHit)) {
-                const PrimRecord rec = prims[cur.ref + idx];
-                leaf_test_one<COUNT>(L, rec, cur.r, cur.ref + idx, lc);
-            }
-        }
-        cur = nxt;
-    }
-}
-
-// ---- traversal ------------------------------------------------------------------
-// ANY = false: closest hit ≙ BoundingVolumeHierarchy::intersect's traversal
-//   (bvh.cpp:299-362) + getIntersecting (:272-293): `t` holds ray.t in/out, `pos`
-//   the array index of the reported primitive (-1: none).
-// ANY = true: shadow query (light.cpp:61-67 only uses the boolean): `t` is the
-//   limit (1.0), pos >= 0 iff something blocks the ray.
-// `active` selects the lanes that carry a ray; ALL lanes of the wave must call.
-// use_bvh = features.enableAccelStructure; when false the whole array is one leaf
-// in the reference's own order (bvh.cpp:303-305; sv.prims_flat).
-//
-// Node phase = depth-first walk with WORK STEALING inside the wave: every lane is
-// a worker with a private deque of (ray slot, node) entries in LDS; a lane whose
-// deque is empty takes the OLDEST entry (the largest pending subtree) of a lane
-// that holds at least two. Because the closest-hit reduction is order-free, any
-// lane may walk any part of any ray's tree; lanes that carry no ray of their own
-// (sparse reflection levels, finished rays) pick up work immediately, so a wave's
-// time is its total work / 64 rather than its longest ray.
-template <bool ANY, bool COUNT>
-RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool active, const RayL& ray, float& t, int32_t& pos,
-    LaneCounters& lc, WaveLds& L)
-{
-    pos = -1;
-    if (ballot(active) == 0)
-        return;
-    const uint32_t lane = lane_id();
-    const PrimRecord* __restrict__ prims = use_bvh ? sv.prims : sv.prims_flat;
-    L.rayA[lane] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
-    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t, 0.0f);
-    L.best[lane] = kNoHit;
-
-    uint32_t bot = 0, sp = 0; // this lane's deque = stack[bot .. sp)
-    uint32_t lq_n = 0;        // leaf-queue fill (wave-uniform)
-    RayL cur = ray;           // ray of the entry being processed (cached in registers)
-    RayInv cur_inv = make_ray_inv(cur);
-    uint32_t cur_r = lane;
-    const bool root_is_leaf = !use_bvh || sv.root_cnt != 0u;
-    if (root_is_leaf) {
-        const uint64_t m = ballot(active);
-        if (active) {
-            const uint32_t o = prefix_count(m);
-            L.lq_ref[o] = use_bvh ? sv.root_ref : 0u;
-            L.lq_rc[o] = lane | ((use_bvh ? sv.root_cnt : sv.n_prims) << 6);
-        }
-        lq_n = (uint32_t)__builtin_popcountll(m);
-    } else if (active) {
-        L.stack[0][lane] = (sv.root_ref << 6) | lane; // the root's own box is never tested (bvh.cpp:313)
-        sp = 1;
-    }
-    wave_lds_fence();
-
-    for (;;) {
-        const uint64_t busy = ballot(sp > bot);
-        if (busy == 0)
-            break;
-        // ---- steal: idle lanes take the oldest entry of lanes holding >= 2 ----------
-        if (busy != ~0ull) {
-            const bool donor = sp - bot >= 2u;
-            const uint64_t donors = ballot(donor);
-            if (donors) {
-                const uint64_t idle = ~busy;
-                const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-                const uint32_t n_don = (uint32_t)__builtin_popcountll(donors);
-                const uint32_t n_x = n_idle < n_don ? n_idle : n_don;
-                const bool is_idle = sp == bot;
-                if (donor) {
-                    const uint32_t k = prefix_count(donors);
-                    if (k < n_x) {
-                        L.xfer[k] = L.stack[bot][lane];
-                        bot++;
-                    }
-                }
-                wave_lds_fence();
-                if (is_idle) {
-                    const uint32_t k = prefix_count(idle);
-                    if (k < n_x) {
-                        L.stack[0][lane] = L.xfer[k];
-                        bot = 0;
-                        sp = 1;
-                    }
-                }
-                wave_lds_fence();
-            }
-        }
-        // ---- node phase: every lane with work pops one internal node ---------------
-        bool leaf_l = false, leaf_r = false;
-        uint32_t l_ref = 0, l_cnt = 0, r_ref = 0, r_cnt = 0, r = 0;
-        if (sp > bot) {
-            sp--;
-            const uint32_t e = L.stack[sp][lane];
-            if (sp == bot)
-                sp = bot = 0;
-            r = e & 63u;
-            if (!(ANY && L.best[r] != kNoHit)) { // a blocked shadow ray needs no more tests
-                if (r != cur_r) {
-                    const float4 a = L.rayA[r], b = L.rayB[r];
-                    cur.o = mk(a.x, a.y, a.z);
-                    cur.d = mk(a.w, b.x, b.y);
-                    cur_inv = make_ray_inv(cur);
-                    cur_r = r;
-                }
-                const NodePair* np = sv.nodes + (e >> 6);
-                const float4 q0 = *reinterpret_cast<const float4*>(&np->l_lo[0]); // l_lo xyz, l_hi x
-                const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
-                const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
-                const uint4 q3 = *reinterpret_cast<const uint4*>(&np->l_ref);
-                const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
-                const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
-                const bool hl = box_hit(llo, lhi, cur, cur_inv);
-                const bool hr = box_hit(rlo, rhi, cur, cur_inv);
-                l_ref = q3.x, l_cnt = q3.y, r_ref = q3.z, r_cnt = q3.w;
-                if (COUNT) {
-                    lc.box += 2;
-                    lc.node_fetch++;
-                }
-                if (hl && l_cnt == 0u) {
-                    L.stack[sp][lane] = (l_ref << 6) | r;
-                    sp++;
-                }
-                if (hr && r_cnt == 0u) {
-                    L.stack[sp][lane] = (r_ref << 6) | r;
-                    sp++;
-                }
-                leaf_l = hl && l_cnt != 0u;
-                leaf_r = hr && r_cnt != 0u;
-            }
-        }
-        const uint64_t ml = ballot(leaf_l), mr = ballot(leaf_r);
-        if (ml | mr) {
-            if (leaf_l) {
-                const uint32_t o = lq_n + prefix_count(ml);
-                L.lq_ref[o] = l_ref;
-                L.lq_rc[o] = r | (l_cnt << 6);
-            }
-            lq_n += (uint32_t)__builtin_popcountll(ml);
-            if (leaf_r) {
-                const uint32_t o = lq_n + prefix_count(mr);
-                L.lq_ref[o] = r_ref;
-                L.lq_rc[o] = r | (r_cnt << 6);
-            }
-            lq_n += (uint32_t)__builtin_popcountll(mr);
-            if (lq_n >= 64u) {
-                wave_lds_fence();
-                do {
-                    lq_n -= 64u;
-                    leaf_phase<ANY, COUNT>(L, prims, lq_n, 64u, lane, lc);
-                } while (lq_n >= 64u);
-                wave_lds_fence();
-            }
-        }
-    }
-    if (lq_n) {
-        wave_lds_fence();
-        leaf_phase<ANY, COUNT>(L, prims, 0u, lq_n, lane, lc);
-    }
-    wave_lds_fence();
-    const unsigned long long key = L.best[lane];
-    if (active && key != kNoHit) {
-        pos = (int32_t)key_index(key);
-        if (!ANY) { // the reported primitive's own t, with its exact bits (-0.0f included)
-            const PrimRecord rec = prims[pos];
-            float tt;
-            if (rec.kind_mat & 0x80000000u)
-                sphere_candidate(rec, ray, t, tt);
-            else
-                tt = tri_plane_t(rec, ray);
-            t = tt;
-        }
-    }
-    wave_lds_fence(); // the caller may reuse L for the next query
+    const uint32_t t0b = __float_as_uint(L.rayB[r].z);
+    const uint32_t bb = (uint32_t)(L.best[r] >> 32);
+    return __uint_as_float(t0b < bb ? t0b : bb);
 }
 
 } // namespace rt

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_level(const LevelArgs a)
     const SceneView& sv = a.sv;
     const uint32_t flags = a.flags;
     const bool use_bvh = (flags & F_ACCEL) != 0;
+    const bool prune = (flags & F_NO_PRUNE) == 0;
 
     // ---- fetch this lane's ray ------------------------------------------------
     bool active = false;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_level(const LevelArgs a)
 
     // ---- closest hit (bvh.intersect, render.cpp:31) -----------------------------
     int32_t pos;
-    traverse<false, COUNT>(sv, use_bvh, active, ray, t, pos, lc, wl);
+    traverse<false, COUNT>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
     const bool hit = active && pos >= 0;
     if (active) {
         if (hit)
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_level(const LevelArgs a)
                     int32_t spos;
                     if (COUNT && hit)
                         rc.shadow++;
-                    traverse<true, COUNT>(sv, use_bvh, hit, sray, st, spos, lc, wl);
+                    traverse<true, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
                     if (spos >= 0)
                         visibility = 0.0f;
                 }
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const IntersectArgs a)
         rc.closest = 1;
     __shared__ WaveLds lds[kBlock / 64];
     int32_t pos;
-    traverse<false, COUNT>(a.sv, (a.flags & F_ACCEL) != 0, active, ray, t, pos, lc, lds[threadIdx.x >> 6]);
+    traverse<false, COUNT>(a.sv, (a.flags & F_ACCEL) != 0, (a.flags & F_NO_PRUNE) == 0, active, ray, t, pos, lc,
+        lds[threadIdx.x >> 6]);
     if (active) {
         const bool hit = pos >= 0;
         HitL h;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void k_div_check(uint32_t seed, uint32_t mode,
             continue;
         RayL r;
         r.o = mk(0, 0, 0), r.d = mk(d, d, d);
-        const RayInv inv = make_ray_inv(r);
+        const RayInv inv = make_ray_inv(r, 1.0f);
         const float q = div_by_ray(n, d, inv.y[0], inv.ok[0]);
         const float ref = n / d;
         const uint32_t ne = (__float_as_uint(n) >> 23) & 0xffu;

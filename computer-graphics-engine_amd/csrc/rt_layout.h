@@ -8,6 +8,7 @@
 // arrays.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h> // float4
 
 namespace rt {
 
@@ -79,6 +80,9 @@ struct SceneView {
     const NodePair* nodes;
     const PrimRecord* prims;      // BVH mode: the reference's visit order (right-first DFS over the leaves)
     const PrimRecord* prims_flat; // brute-force mode (enableAccelStructure off): the reference's array order
+    // the same two arrays viewed as six 16-byte words per record (leaf-phase loads)
+    const float4* chunks;
+    const float4* chunks_flat;
     const uint32_t* tri_vidx;   // prim_id*3 → global vertex index (triangles only)
     const float* vnormal;       // global vertex normals, xyz
     const float* vtexcoord;     // global vertex texcoords, uv
@@ -89,6 +93,10 @@ struct SceneView {
     uint32_t n_lights;
     uint32_t root_ref, root_cnt; // child reference of the root (never box-tested: bvh.cpp:313)
     uint32_t n_prims;
+    uint32_t prune_ok; // 0 when the scene holds spheres (rt_device.h: Pruning)
+    float extent;      // largest |coordinate| of any vertex
+    unsigned long long* stamps; // diagnostic builds (-DRT_STAMPS) only, else NULL
+    uint32_t leaf_flush; // leaf-queue fill at which the wave switches to the leaf phase (tuning, 2..64)
 };
 
 } // namespace rt

@@ -2,7 +2,7 @@
 // and reflection rays. Each function names the reference code it restates;
 // operation order is the reference's (see rt_device.h on arithmetic).
 #pragma once
-#include "rt_device.h"
+#include "rt_traverse.h"
 
 namespace rt {
 
@@ -15,6 +15,7 @@ enum : uint32_t {
     F_TEXTURE = 1u << 5,
     F_ACCEL = 1u << 6,
     F_BILINEAR = 1u << 7,
+    F_NO_PRUNE = 1u << 8, // reference policy: visit every leaf whose boxes are hit (rt_set_option "unpruned")
 };
 
 struct HitL { // one lane's HitInfo (src/common.h:14-19) without the unused members

@@ -1,0 +1,366 @@
+// rt_traverse.h — BVH traversal of one wave's rays (closest hit / shadow query).
+//
+// Building blocks and the order-free reduction argument: rt_device.h.
+//
+//  NODE phase. Every lane is a worker with a private deque of (ray slot, node
+//    pair) entries in LDS. A worker pops its newest entry, gathers the 64-byte
+//    NodePair, runs the two slab tests for that ray and pushes the internal
+//    children it must descend into (nearer child on top). A lane whose deque is
+//    empty takes the OLDEST entry (the largest pending subtree) of a lane that
+//    holds at least two, so lanes that carry no ray of their own (sparse
+//    reflection levels, finished rays) pick up work at once and a wave's time is
+//    its total work / 64 rather than its longest ray.
+//    (A wave-level "packet" walk with scalar node loads was measured too: on the
+//    819 200-triangle bench scene it is 2.5x slower — its visits form one serial
+//    chain per wave — and was dropped; profiles/r01_notes.md.)
+//  LEAF phase. Leaf children are parked as (ray, leaf) pairs in a per-wave queue;
+//    half a wave tests one pair, one primitive per lane. Records of a leaf are
+//    stored chunk-major (rt_layout.h: LeafChunks) so that lane i's k-th 16-byte
+//    load sits next to lane i+1's: six fully coalesced loads per pair.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+// ---- leaf phase -----------------------------------------------------------------
+struct LeafSlot {
+    float4 c[6];                // the primitive's record, chunk by chunk
+    uint32_t r, ref, cnt, cmax; // ray slot, first primitive, this half's count, max of both halves
+    bool live;                  // this lane holds a record of the first 32 primitives
+};
+
+RT_DEV PrimRecord record_from_chunks(const float4 c[6])
+{
+    PrimRecord rec;
+    rec.n[0] = c[0].x, rec.n[1] = c[0].y, rec.n[2] = c[0].z, rec.D = c[0].w;
+    rec.e0[0] = c[1].x, rec.e0[1] = c[1].y, rec.e0[2] = c[1].z, rec.e1[0] = c[1].w;
+    rec.e1[1] = c[2].x, rec.e1[2] = c[2].y, rec.e2[0] = c[2].z, rec.e2[1] = c[2].w;
+    rec.e2[2] = c[3].x, rec.v0[0] = c[3].y, rec.v0[1] = c[3].z, rec.v0[2] = c[3].w;
+    rec.v1[0] = c[4].x, rec.v1[1] = c[4].y, rec.v1[2] = c[4].z, rec.v2[0] = c[4].w;
+    rec.v2[1] = c[5].x, rec.v2[2] = c[5].y;
+    rec.prim_id = (int32_t)__float_as_uint(c[5].z);
+    rec.kind_mat = __float_as_uint(c[5].w);
+    return rec;
+}
+
+// the six 16-byte words of primitive (ref + i). (A chunk-major per-leaf layout that
+// makes these loads contiguous across lanes was measured 11 % SLOWER than the plain
+// 96-byte records — the phase is latency-, not transaction-bound — and dropped.)
+RT_DEV void load_chunks(const float4* __restrict__ chunks, uint32_t ref, uint32_t /*cnt*/, uint32_t i, float4 c[6])
+{
+    const float4* base = chunks + ((size_t)ref + i) * 6u;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        c[k] = base[k];
+}
+
+template <bool ANY>
+RT_DEV void leaf_fetch(const WaveLds& L, const float4* __restrict__ chunks, uint32_t my_ref, uint32_t my_rc,
+    float my_lb, bool prune, uint32_t k, uint32_t n, bool upper, uint32_t sub, LeafSlot& s)
+{
+    const uint32_t ref0 = read_lane(my_ref, k), rc0 = read_lane(my_rc, k);
+    const uint32_t k1 = k + 1 < n ? k + 1 : k;
+    const uint32_t ref1 = read_lane(my_ref, k1), rc1 = (k + 1 < n) ? read_lane(my_rc, k1) : 0u;
+    const float lb0 = __uint_as_float(read_lane(__float_as_uint(my_lb), k));
+    const float lb1 = __uint_as_float(read_lane(__float_as_uint(my_lb), k1));
+    s.ref = upper ? ref1 : ref0;
+    const uint32_t rc = upper ? rc1 : rc0;
+    const float lb = upper ? lb1 : lb0;
+    s.r = rc & 63u;
+    const uint32_t cnt_all = rc >> 6;
+    s.cnt = cnt_all;
+    if (ANY ? (L.best[s.r] != kNoHit) : (prune && lb > ray_limit(L, s.r)))
+        s.cnt = 0; // blocked shadow ray / leaf that cannot hold the closest candidate any more
+    // wave-uniform loop bound for leaves with more than 32 primitives
+    const uint32_t c_lo = read_lane(s.cnt, 0), c_hi = read_lane(s.cnt, 32);
+    s.cmax = c_lo > c_hi ? c_lo : c_hi;
+    s.live = sub < s.cnt;
+    if (s.live)
+        load_chunks(chunks, s.ref, cnt_all, sub, s.c);
+    s.cnt = s.cnt ? cnt_all : 0u;
+}
+
+template <bool COUNT>
+RT_DEV void leaf_test_one(WaveLds& L, const float4 c[6], uint32_t r, uint32_t index, LaneCounters& lc)
+{
+    const PrimRecord rec = record_from_chunks(c);
+    const float4 a = L.rayA[r], b = L.rayB[r];
+    RayL ray;
+    ray.o = mk(a.x, a.y, a.z);
+    ray.d = mk(a.w, b.x, b.y);
+    const float t0 = b.z;
+    float tt;
+    bool cand;
+    const bool sphere = (rec.kind_mat & 0x80000000u) != 0u;
+    if (!sphere) {
+        cand = tri_candidate(rec, ray, t0, tt);
+        if (COUNT)
+            lc.tri++;
+    } else {
+        cand = sphere_candidate(rec, ray, t0, tt);
+        if (COUNT)
+            lc.sph++;
+    }
+    if (COUNT)
+        lc.tri_fetch++;
+    if (cand)
+        atomicMin(&L.best[r], make_key(tt, index, sphere));
+}
+
+// Entries [first, first + n) of the wave's leaf queue, n <= 64: two entries per
+// step, one per half-wave, one primitive per lane; the fetch of step k+1 is issued
+// before step k is tested.
+template <bool ANY, bool COUNT>
+RT_DEV void leaf_phase(WaveLds& L, const float4* __restrict__ chunks, uint32_t first, uint32_t n, uint32_t lane,
+    bool prune, LaneCounters& lc)
+{
+    uint32_t my_ref = 0, my_rc = 0;
+    float my_lb = 0.0f;
+    if (lane < n) {
+        my_ref = L.lq_ref[first + lane];
+        my_rc = L.lq_rc[first + lane];
+        my_lb = L.lq_lb[first + lane];
+    }
+    const bool upper = lane >= 32u;
+    const uint32_t sub = lane & 31u;
+    LeafSlot cur, nxt;
+    leaf_fetch<ANY>(L, chunks, my_ref, my_rc, my_lb, prune, 0u, n, upper, sub, cur);
+    for (uint32_t k = 0; k < n; k += 2) {
+        nxt.live = false;
+        nxt.cmax = 0;
+        if (k + 2 < n)
+            leaf_fetch<ANY>(L, chunks, my_ref, my_rc, my_lb, prune, k + 2, n, upper, sub, nxt);
+        if (cur.live)
+            leaf_test_one<COUNT>(L, cur.c, cur.r, cur.ref + sub, lc);
+        // leaves larger than 32 primitives (brute-force mode, very large meshes)
+        for (uint32_t base = 32u; base < cur.cmax; base += 32u) {
+            const uint32_t idx = base + sub;
+            if (idx < cur.cnt && !(ANY && L.best[cur.r] != kNoHit)) {
+                float4 c[6];
+                load_chunks(chunks, cur.ref, cur.cnt, idx, c);
+                leaf_test_one<COUNT>(L, c, cur.r, cur.ref + idx, lc);
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// State shared by the engines of one traverse() call.
+template <bool ANY, bool COUNT>
+struct Walk {
+    const SceneView& sv;
+    WaveLds& L;
+    const float4* __restrict__ chunks;
+    LaneCounters& lc;
+    uint32_t lane;
+    bool prune;
+    uint32_t lq_n; // leaf-queue fill (wave-uniform)
+    // ray cached in registers (slot cur_r of the LDS ray table)
+    RayL cur;
+    RayInv cur_inv;
+    uint32_t cur_r;
+
+    RT_DEV void load_ray(uint32_t r)
+    {
+        if (r != cur_r) {
+            const float4 a = L.rayA[r], b = L.rayB[r];
+            cur.o = mk(a.x, a.y, a.z);
+            cur.d = mk(a.w, b.x, b.y);
+            cur_inv = make_ray_inv(cur, sv.extent);
+            cur_r = r;
+        }
+    }
+
+    // append the lanes' (ray r, leaf ref/cnt, lb) pairs for which `want` is set
+    RT_DEV void queue_leaves(bool want, uint32_t r, uint32_t ref, uint32_t cnt, float lb)
+    {
+        const uint64_t m = ballot(want);
+        if (m) {
+            if (want) {
+                const uint32_t o = lq_n + prefix_count(m);
+                L.lq_ref[o] = ref;
+                L.lq_rc[o] = r | (cnt << 6);
+                L.lq_lb[o] = lb;
+            }
+            lq_n += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+
+    // Flush early: a leaf step keeps all 64 lanes busy with any two entries, and the
+    // sooner a leaf is tested the sooner its hit prunes the rest of the tree.
+    RT_DEV void flush_leaves(uint32_t threshold)
+    {
+        if (lq_n >= threshold && lq_n > 0u) {
+            wave_lds_fence();
+            while (lq_n > 0u) {
+                const uint32_t n = lq_n < 64u ? lq_n : 64u;
+                lq_n -= n;
+                leaf_phase<ANY, COUNT>(L, chunks, lq_n, n, lane, prune, lc);
+            }
+            wave_lds_fence();
+        }
+    }
+
+    // Box tests of one node pair for ray slot r (already cached): returns which
+    // children to descend into, with their lower bounds.
+    RT_DEV void test_pair(const float llo[3], const float lhi[3], const float rlo[3], const float rhi[3], uint32_t r,
+        bool& hl, bool& hr, float& lb_l, float& lb_r)
+    {
+        hl = box_hit(llo, lhi, cur, cur_inv, lb_l);
+        hr = box_hit(rlo, rhi, cur, cur_inv, lb_r);
+        if (COUNT) {
+            lc.box += 2;
+            lc.node_fetch++;
+        }
+        if (prune) { // shadow rays: against the initial limit (t0 = 1)
+            const float lim = ANY ? L.rayB[r].z : ray_limit(L, r);
+            hl = hl && !(lb_l > lim);
+            hr = hr && !(lb_r > lim);
+        }
+    }
+
+    // ---- LANE engine: private deques in rows [row0, ...) of L.stack, work stealing ----
+    // On entry lanes with `seed` hold one entry (node pair `node`, own ray, bound lb).
+    RT_DEV void lane_engine(uint32_t row0, bool seed, uint32_t node, float seed_lb)
+    {
+        uint32_t bot = 0, sp = 0; // this lane's deque = rows row0 + [bot .. sp)
+        if (seed) {
+            L.stack[row0][lane] = (node << 6) | lane;
+            L.stack_lb[row0][lane] = seed_lb;
+            sp = 1;
+        }
+        wave_lds_fence();
+        for (;;) {
+            const uint64_t busy = ballot(sp > bot);
+            if (busy == 0)
+                break;
+            if (busy != ~0ull) { // steal: idle lanes take the oldest entry of lanes holding >= 2
+                const bool donor = sp - bot >= 2u;
+                const uint64_t donors = ballot(donor);
+                if (donors) {
+                    const uint64_t idle = ~busy;
+                    const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+                    const uint32_t n_don = (uint32_t)__builtin_popcountll(donors);
+                    const uint32_t n_x = n_idle < n_don ? n_idle : n_don;
+                    const bool is_idle = sp == bot;
+                    if (donor) {
+                        const uint32_t k = prefix_count(donors);
+                        if (k < n_x) {
+                            L.xfer[k] = L.stack[row0 + bot][lane];
+                            L.xfer_lb[k] = L.stack_lb[row0 + bot][lane];
+                            bot++;
+                        }
+                    }
+                    wave_lds_fence();
+                    if (is_idle) {
+                        const uint32_t k = prefix_count(idle);
+                        if (k < n_x) {
+                            L.stack[row0][lane] = L.xfer[k];
+                            L.stack_lb[row0][lane] = L.xfer_lb[k];
+                            bot = 0;
+                            sp = 1;
+                        }
+                    }
+                    wave_lds_fence();
+                }
+            }
+            bool leaf_l = false, leaf_r = false;
+            uint32_t l_ref = 0, l_cnt = 0, r_ref = 0, r_cnt = 0, r = 0;
+            float lb_l = 0.0f, lb_r = 0.0f;
+            if (sp > bot) {
+                sp--;
+                const uint32_t e = L.stack[row0 + sp][lane];
+                const float e_lb = L.stack_lb[row0 + sp][lane];
+                if (sp == bot)
+                    sp = bot = 0;
+                r = e & 63u;
+                const bool skip = ANY ? (L.best[r] != kNoHit) : (prune && e_lb > ray_limit(L, r));
+                if (!skip) {
+                    load_ray(r);
+                    const NodePair* np = sv.nodes + (e >> 6);
+                    const float4 q0 = *reinterpret_cast<const float4*>(&np->l_lo[0]); // l_lo xyz, l_hi x
+                    const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
+                    const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
+                    const uint4 q3 = *reinterpret_cast<const uint4*>(&np->l_ref);
+                    const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
+                    const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
+                    bool hl, hr;
+                    test_pair(llo, lhi, rlo, rhi, r, hl, hr, lb_l, lb_r);
+                    l_ref = q3.x, l_cnt = q3.y, r_ref = q3.z, r_cnt = q3.w;
+                    const bool push_l = hl && l_cnt == 0u, push_r = hr && r_cnt == 0u;
+                    // the nearer child goes on top (popped first): finds close hits early
+                    const bool l_first = push_l && (!push_r || lb_l > lb_r);
+                    if (push_l && l_first) {
+                        L.stack[row0 + sp][lane] = (l_ref << 6) | r;
+                        L.stack_lb[row0 + sp][lane] = lb_l;
+                        sp++;
+                    }
+                    if (push_r) {
+                        L.stack[row0 + sp][lane] = (r_ref << 6) | r;
+                        L.stack_lb[row0 + sp][lane] = lb_r;
+                        sp++;
+                    }
+                    if (push_l && !l_first) {
+                        L.stack[row0 + sp][lane] = (l_ref << 6) | r;
+                        L.stack_lb[row0 + sp][lane] = lb_l;
+                        sp++;
+                    }
+                    leaf_l = hl && l_cnt != 0u;
+                    leaf_r = hr && r_cnt != 0u;
+                }
+            }
+            queue_leaves(leaf_l, r, l_ref, l_cnt, lb_l);
+            queue_leaves(leaf_r, r, r_ref, r_cnt, lb_r);
+            flush_leaves(sv.leaf_flush);
+        }
+    }
+};
+
+// ---- traversal ------------------------------------------------------------------
+// ANY = false: closest hit ≙ BoundingVolumeHierarchy::intersect's traversal
+//   (bvh.cpp:299-362) + getIntersecting (:272-293): `t` holds ray.t in/out, `pos`
+//   the array index of the reported primitive (-1: none).
+// ANY = true: shadow query (light.cpp:61-67 only uses the boolean): `t` is the
+//   limit (1.0), pos >= 0 iff something blocks the ray.
+// `active` selects the lanes that carry a ray; ALL lanes of the wave must call.
+// use_bvh = features.enableAccelStructure; when false the whole array is one leaf
+// in the reference's own order (bvh.cpp:303-305; sv.chunks_flat).
+template <bool ANY, bool COUNT>
+RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active, const RayL& ray, float& t,
+    int32_t& pos, LaneCounters& lc, WaveLds& L)
+{
+    pos = -1;
+    const uint64_t act = ballot(active);
+    if (act == 0)
+        return;
+    const uint32_t lane = lane_id();
+    prune = prune && use_bvh && sv.prune_ok != 0u;
+    L.rayA[lane] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t, 0.0f);
+    L.best[lane] = kNoHit;
+    Walk<ANY, COUNT> w { sv, L, use_bvh ? sv.chunks : sv.chunks_flat, lc, lane, prune, 0u, ray,
+        make_ray_inv(ray, sv.extent), lane };
+
+    if (!use_bvh || sv.root_cnt != 0u) // the root is a leaf / brute force: one pair per ray
+        w.queue_leaves(active, lane, use_bvh ? sv.root_ref : 0u, use_bvh ? sv.root_cnt : sv.n_prims, 0.0f);
+    else // the root's own box is never tested (bvh.cpp:313)
+        w.lane_engine(0u, active, sv.root_ref, 0.0f);
+    w.flush_leaves(1u);
+    wave_lds_fence();
+    const unsigned long long key = L.best[lane];
+    if (active && key != kNoHit) {
+        pos = (int32_t)key_index(key);
+        if (!ANY) { // the reported primitive's own t, with its exact bits (-0.0f included)
+            const PrimRecord rec = (use_bvh ? sv.prims : sv.prims_flat)[pos];
+            float tt;
+            if (rec.kind_mat & 0x80000000u)
+                sphere_candidate(rec, ray, t, tt);
+            else
+                tt = tri_plane_t(rec, ray);
+            t = tt;
+        }
+    }
+    wave_lds_fence(); // the caller may reuse L for the next query
+}
+
+} // namespace rt

@@ -185,6 +185,12 @@ const char* rt_last_error(void);
  * HIP runtime is unusable. The product path never falls back to the CPU. */
 int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len);
 
+/* Process-wide options. "unpruned" = 1: traverse with the reference's own policy
+ * (every leaf whose boxes are hit is tested, src/bounding_volume_hierarchy.cpp:334-355);
+ * 0 (default): additionally skip subtrees that provably cannot hold the closest
+ * candidate (csrc/rt_device.h "Pruning") — results are identical bit for bit. */
+int rt_set_option(const char* name, int value);
+
 /* Select the HIP device used by subsequent creates on this thread. */
 int rt_set_device(int device);
 

@@ -267,6 +267,42 @@ def test_knot_reflections_reduced_resolution(rt, oracle, scenes, built):
     assert cnt.rays_primary == W * H
 
 
+@pytest.mark.parametrize("scene_key,W,H", [("monkey", 512, 512), ("teapot", 384, 384), ("cornell", 256, 256),
+                                           ("knot", 480, 270)])
+def test_pruned_traversal_equals_reference_policy(rt, oracle, abi, scenes, built, scene_key, W, H):
+    """The default traversal skips subtrees that provably cannot hold the closest
+    candidate (csrc/rt_device.h "Pruning"); rt_set_option("unpruned", 1) visits
+    every leaf the reference visits. Both must give the same bits — hit records of
+    the frame and of random rays (incl. finite t limits) — with fewer tests."""
+    f = abi.Features.make(enableShading=1, enableRecursive=1, enableHardShadow=1, enableAccelStructure=1)
+    p = abi.RenderParams.make(depth=3)
+    data, sc, bvh, ob = built(scene_key, f)
+    cam = rt.camera(*scenes.default_camera_args(W, H))
+    rng = np.random.default_rng(5)
+    rays = make_rays(abi, rng, 20000, scale=2.5)
+    rays["t"][:5000] = rng.uniform(0.2, 4.0, 5000).astype(np.float32)
+    res = {}
+    for unpruned in (1, 0):
+        rt.set_option("unpruned", unpruned)
+        try:
+            tb, pr = rt.render_hits(bvh, cam, f, W, H)
+            rgb, cnt = rt.render(bvh, cam, f, p, W, H, count=True)
+            r2, h2 = rt.intersect_batch(bvh, rays, f)
+        finally:
+            rt.set_option("unpruned", 0)
+        res[unpruned] = (tb, pr, rgb, cnt, r2, h2)
+    a, b = res[1], res[0]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(np.isnan(a[2]), np.isnan(b[2]))
+    assert np.array_equal(bits(a[2])[~np.isnan(a[2])], bits(b[2])[~np.isnan(b[2])]), "colours must be bit-identical"
+    assert np.array_equal(bits(a[4]["t"]), bits(b[4]["t"])) and np.array_equal(a[5]["prim"], b[5]["prim"])
+    assert a[3].rays == b[3].rays
+    assert b[3].tri_tests < a[3].tri_tests and b[3].box_tests < a[3].box_tests, "pruning must save work"
+    # the unpruned counts are the reference policy's (closest-hit part; shadow rays stop early)
+    _, _, _, ocnt = oracle.render(ob, oracle.camera(*scenes.default_camera_args(W, H)), f, p, W, H)
+    assert a[3].rays_ref_equiv == ocnt.rays
+
+
 def test_slab_division_is_the_ieee_quotient(rt):
     """The slab test divides by the ray direction through a per-ray reciprocal
     (q0 = n*y, r = fma(-d, q0, n), q = fma(r, y, q0)); every quotient must have the

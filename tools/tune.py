@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Sweep a runtime tuning option of the library on the bench workload (one process,
+interleaved rounds — guide §5.4 rule 24). Usage: tools/tune.py leaf_flush 2 4 8 16 32 64"""
+import importlib, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import torch
+capi = importlib.import_module("computer-graphics-engine_amd.capi")
+scenes = importlib.import_module("computer-graphics-engine_amd.scenes")
+sharding = importlib.import_module("computer-graphics-engine_amd.sharding")
+
+name = sys.argv[1]
+values = [int(v) for v in sys.argv[2:]]
+workload = "C3"
+rt = capi.Library()
+cfg = scenes.CONFIGS[workload]
+f, p = cfg.make_features(), cfg.make_params()
+data = scenes.get_scene(cfg.scene)
+bvh = rt.bvh(rt.scene(data), f)
+cam = rt.camera(*scenes.default_camera_args(cfg.width, cfg.height))
+stream = torch.cuda.current_stream().cuda_stream
+R = sharding.StripRenderer(rt, bvh, cam, f, p, cfg.width, cfg.height)
+res = {v: [] for v in values}
+cnts = {}
+for rnd in range(4):
+    for v in values:
+        rt.set_option(name, v)
+        if rnd == 0:
+            c = R.count_rays(stream)
+            cnts[v] = c
+        for _ in range(3):
+            R.step(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            R.step(stream)
+        torch.cuda.synchronize()
+        res[v].append((time.perf_counter() - t0) / 20 * 1e3)
+for v in values:
+    c = cnts[v]
+    print(f"{name}={v:3d}  ms/frame median {np.median(res[v]):.3f} min {min(res[v]):.3f}  box {c['box_tests']/1e6:.1f}M tri {c['tri_tests']/1e6:.1f}M rays {c['rays']}")
