@@ -46,6 +46,18 @@ def deinterleave_numpy(gathered: np.ndarray, height: int, strip_rows: int) -> np
     return frame
 
 
+def gather_strips(gathered, local):
+    """The ONE exchange step of a frame: every rank's packed strips → every rank.
+    RCCL (backend nccl) takes the flat all-gather; gloo (CPU tests) has no
+    _allgather_base, so it gets the list form over views of the same buffer."""
+    import torch.distributed as dist
+
+    if dist.get_backend() == "gloo":
+        dist.all_gather(list(gathered.unbind(0)), local)
+    else:
+        dist.all_gather_into_tensor(gathered, local)
+
+
 class StripRenderer:
     """One rank's share of a frame + the gather. `step()` enqueues everything on
     the given HIP stream without host synchronisation."""
@@ -68,11 +80,9 @@ class StripRenderer:
             self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
                                   stream=stream)
             return
-        import torch.distributed as dist
-
         self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local.data_ptr(),
                               rows=self.rows, packed=True, stream=stream)
-        dist.all_gather_into_tensor(self.gathered, self.local)
+        gather_strips(self.gathered, self.local)
         self.rt.deinterleave_strips(self.gathered.data_ptr(), self.frame.data_ptr(), self.W, self.H,
                                     self.strip_rows, self.world, stream=stream)
 
