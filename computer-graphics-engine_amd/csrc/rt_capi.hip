@@ -353,9 +353,13 @@ int rt_set_option(const char* name, int value)
         g_unpruned.store(value != 0);
         return RT_OK;
     }
+    if (name && strcmp(name, "lds_pad") == 0) { // tuning experiment: extra dynamic LDS lowers occupancy
+        rt::g_lds_pad = (uint32_t)value;
+        return RT_OK;
+    }
     if (name && strcmp(name, "leaf_flush") == 0) {
-        if (value < 1 || value > 64)
-            return fail(RT_ERR_INVALID, "rt_set_option: leaf_flush must be in [1, 64]");
+        if (value < 1 || value > (int)rt::kLeafFlushMax)
+            return fail(RT_ERR_INVALID, "rt_set_option: leaf_flush must be in [1, 16]");
         g_leaf_flush.store(value);
         return RT_OK;
     }

@@ -105,24 +105,36 @@ struct LaneCounters {
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
 };
 
-// Per-wave LDS working set (13.5 KiB): ray table, best-key slots, the per-lane
+// Per-wave LDS working set (8.4 KiB): ray table, best-key slots, the per-lane
 // deques (slot [level][lane]: conflict-free; entry = node pair index << 6 | ray
 // slot, plus the entry's distance lower bound) and the (ray, leaf) pair queue.
 constexpr uint32_t kStackLevels = 16; // MAX_DEPTH = 16 levels ⇒ at most 15 internal levels pending
-constexpr uint32_t kLeafQueue = 192;  // < 64 left over + at most 128 appended per node step
+constexpr uint32_t kLeafFlushMax = 16; // largest leaf_flush threshold (SceneView::leaf_flush)
+constexpr uint32_t kLeafQueue = 144;   // < kLeafFlushMax left over + at most 128 appended per node step
 struct alignas(16) WaveLds {
     float4 rayA[64]; // ox oy oz dx
     float4 rayB[64]; // dy dz t0 -
     unsigned long long best[64];
-    uint32_t stack[kStackLevels][64];
-    float stack_lb[kStackLevels][64];
+    uint32_t stack[kStackLevels][64]; // packed entries, see pack_entry()
     uint32_t lq_ref[kLeafQueue];
     uint32_t lq_rc[kLeafQueue]; // ray slot (6 bits) | count << 6
     float lq_lb[kLeafQueue];
     uint32_t xfer[64];          // work-stealing hand-over slots
-    float xfer_lb[64];
 };
-static_assert(sizeof(WaveLds) == 13568, "WaveLds");
+static_assert(sizeof(WaveLds) == 8640, "WaveLds"); // x4 waves = 33.75 KiB per block: 4 blocks per CU
+
+// A deque entry in 32 bits: [31:21] lower bound, [20:6] node pair index, [5:0] ray slot.
+// MAX_DEPTH = 16 levels caps a tree at 32 767 internal nodes (15 bits). The bound keeps
+// the top 11 bits of the non-negative float (8 exponent + 3 mantissa bits), truncated,
+// i.e. rounded DOWN — still a valid lower bound, at most 12.5 % looser.
+RT_DEV uint32_t pack_entry(uint32_t node, uint32_t ray, float lb)
+{
+    const uint32_t b = lb > 0.0f ? (__float_as_uint(lb) >> 20) : 0u; // NaN / negative: no bound
+    return (b << 21) | (node << 6) | ray;
+}
+RT_DEV float entry_lb(uint32_t e) { return __uint_as_float((e >> 21) << 20); }
+RT_DEV uint32_t entry_node(uint32_t e) { return (e >> 6) & 0x7fffu; }
+RT_DEV uint32_t entry_ray(uint32_t e) { return e & 63u; }
 
 // ---- primitive tests (decls src/intersect.h:5-16) -----
 

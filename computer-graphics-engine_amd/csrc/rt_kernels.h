@@ -74,6 +74,7 @@ struct IntersectArgs {
     rt_counters* counters;
 };
 
+extern uint32_t g_lds_pad;
 void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s);
 void launch_fold(const FoldArgs& a, hipStream_t s);
 void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s);

@@ -25,6 +25,9 @@ namespace rt {
 namespace {
 
 constexpr int kBlock = 256; // 4 waves, one 8x8 pixel tile (or up to 64 queued rays) each
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument: 128 VGPRs (31 dwords spilled), 4 waves per SIMD: +3 % (tools/ab.py)
+#endif
 constexpr uint32_t kMinWaves = 4096;      // aim for >= 4 busy waves per SIMD on sparse levels
 constexpr uint32_t kMinRaysPerWave = 4;
 
@@ -101,7 +104,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_level(const LevelArgs a)
+__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const LevelArgs a)
 {
     const uint32_t lane = lane_id();
     const uint32_t wave = uni(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
@@ -467,6 +470,8 @@ uint64_t camera_waves(const CameraArgs& c)
 
 } // namespace
 
+uint32_t g_lds_pad = 0; // tuning experiment: extra dynamic LDS per block lowers occupancy
+
 void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
 {
     uint64_t waves;
@@ -482,7 +487,7 @@ void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
     if (count)
         hipLaunchKernelGGL(k_trace_level<true>, dim3(grid), dim3(kBlock), 0, s, a);
     else
-        hipLaunchKernelGGL(k_trace_level<false>, dim3(grid), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(k_trace_level<false>, dim3(grid), dim3(kBlock), g_lds_pad, s, a);
 }
 
 void launch_fold(const FoldArgs& a, hipStream_t s)

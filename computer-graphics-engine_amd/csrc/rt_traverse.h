@@ -14,9 +14,8 @@
 //    819 200-triangle bench scene it is 2.5x slower — its visits form one serial
 //    chain per wave — and was dropped; profiles/r01_notes.md.)
 //  LEAF phase. Leaf children are parked as (ray, leaf) pairs in a per-wave queue;
-//    half a wave tests one pair, one primitive per lane. Records of a leaf are
-//    stored chunk-major (rt_layout.h: LeafChunks) so that lane i's k-th 16-byte
-//    load sits next to lane i+1's: six fully coalesced loads per pair.
+//    half a wave tests one pair, one primitive per lane (six 16-byte loads of its
+//    96-byte record), the next pair's records are prefetched.
 #pragma once
 #include "rt_device.h"
 
@@ -225,8 +224,7 @@ struct Walk {
     {
         uint32_t bot = 0, sp = 0; // this lane's deque = rows row0 + [bot .. sp)
         if (seed) {
-            L.stack[row0][lane] = (node << 6) | lane;
-            L.stack_lb[row0][lane] = seed_lb;
+            L.stack[row0][lane] = pack_entry(node, lane, seed_lb);
             sp = 1;
         }
         wave_lds_fence();
@@ -247,7 +245,6 @@ struct Walk {
                         const uint32_t k = prefix_count(donors);
                         if (k < n_x) {
                             L.xfer[k] = L.stack[row0 + bot][lane];
-                            L.xfer_lb[k] = L.stack_lb[row0 + bot][lane];
                             bot++;
                         }
                     }
@@ -256,7 +253,6 @@ struct Walk {
                         const uint32_t k = prefix_count(idle);
                         if (k < n_x) {
                             L.stack[row0][lane] = L.xfer[k];
-                            L.stack_lb[row0][lane] = L.xfer_lb[k];
                             bot = 0;
                             sp = 1;
                         }
@@ -270,14 +266,14 @@ struct Walk {
             if (sp > bot) {
                 sp--;
                 const uint32_t e = L.stack[row0 + sp][lane];
-                const float e_lb = L.stack_lb[row0 + sp][lane];
+                const float e_lb = entry_lb(e);
                 if (sp == bot)
                     sp = bot = 0;
-                r = e & 63u;
+                r = entry_ray(e);
                 const bool skip = ANY ? (L.best[r] != kNoHit) : (prune && e_lb > ray_limit(L, r));
                 if (!skip) {
                     load_ray(r);
-                    const NodePair* np = sv.nodes + (e >> 6);
+                    const NodePair* np = sv.nodes + entry_node(e);
                     const float4 q0 = *reinterpret_cast<const float4*>(&np->l_lo[0]); // l_lo xyz, l_hi x
                     const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
                     const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
@@ -291,18 +287,15 @@ struct Walk {
                     // the nearer child goes on top (popped first): finds close hits early
                     const bool l_first = push_l && (!push_r || lb_l > lb_r);
                     if (push_l && l_first) {
-                        L.stack[row0 + sp][lane] = (l_ref << 6) | r;
-                        L.stack_lb[row0 + sp][lane] = lb_l;
+                        L.stack[row0 + sp][lane] = pack_entry(l_ref, r, lb_l);
                         sp++;
                     }
                     if (push_r) {
-                        L.stack[row0 + sp][lane] = (r_ref << 6) | r;
-                        L.stack_lb[row0 + sp][lane] = lb_r;
+                        L.stack[row0 + sp][lane] = pack_entry(r_ref, r, lb_r);
                         sp++;
                     }
                     if (push_l && !l_first) {
-                        L.stack[row0 + sp][lane] = (l_ref << 6) | r;
-                        L.stack_lb[row0 + sp][lane] = lb_l;
+                        L.stack[row0 + sp][lane] = pack_entry(l_ref, r, lb_l);
                         sp++;
                     }
                     leaf_l = hl && l_cnt != 0u;
