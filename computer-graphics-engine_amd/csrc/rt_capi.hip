@@ -29,6 +29,8 @@ std::mutex g_host_call_mu;
 std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
+// rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
+std::atomic<int> g_tile_wlog { 3 }, g_tile_hlog { 3 }, g_min_waves { 4096 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -222,6 +224,7 @@ rt::CameraArgs camera_args(const rt_camera& c, int32_t w, int32_t h)
     a.half_w = c.half_w, a.half_h = c.half_h;
     a.width = w, a.height = h;
     a.rows = nullptr, a.row0 = 0, a.n_rows = h;
+    a.tile_wlog = (uint32_t)g_tile_wlog.load(), a.tile_hlog = (uint32_t)g_tile_hlog.load();
     return a;
 }
 
@@ -252,6 +255,7 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.flags = flags;
     a.depth = n_levels - 1;
     a.parallelogram_n = p.parallelogram_n, a.segment_n = p.segment_n, a.seed = p.seed;
+    a.min_waves = (uint32_t)g_min_waves.load();
     a.cam = cam;
     a.state = sc.state.p;
     a.n_items = n_items;
@@ -351,6 +355,18 @@ int rt_set_option(const char* name, int value)
 {
     if (name && strcmp(name, "unpruned") == 0) {
         g_unpruned.store(value != 0);
+        return RT_OK;
+    }
+    if (name && (strcmp(name, "tile_wlog") == 0 || strcmp(name, "tile_hlog") == 0)) {
+        if (value < 0 || value > 3)
+            return fail(RT_ERR_INVALID, "rt_set_option: tile_wlog / tile_hlog must be in [0, 3]");
+        (name[5] == 'w' ? g_tile_wlog : g_tile_hlog).store(value);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "min_waves") == 0) {
+        if (value < 1)
+            return fail(RT_ERR_INVALID, "rt_set_option: min_waves must be >= 1");
+        g_min_waves.store(value);
         return RT_OK;
     }
     if (name && strcmp(name, "lds_pad") == 0) { // tuning experiment: extra dynamic LDS lowers occupancy

@@ -248,7 +248,7 @@ RT_DEV bool tri_candidate(const PrimRecord& rec, const RayL& r, float t0, float&
     tt = tri_plane_t(rec, r);
     if (!(tt >= 0.0f))
         return false;
-    if (!(t0 >= tt))
+    if (!(t0 >= tt)) // t0 may be any value in [best t so far, initial ray.t]: "<=" keeps equal-t ties
         return false;
     const V3 p = r.d * tt + r.o;
     if (!(dot(ld3(rec.e0), p - ld3(rec.v0)) >= 0.0f))

@@ -25,6 +25,7 @@ struct CameraArgs {
     int32_t width, height;
     const int32_t* rows; // device list of image rows, NULL → row0 + local row
     int32_t row0, n_rows;
+    uint32_t tile_wlog, tile_hlog; // primary tile = 2^wlog x 2^hlog pixels per wave (<= 64)
 };
 
 // One recursion level of the flattened Whitted recursion (k_trace_level).
@@ -39,6 +40,7 @@ struct LevelArgs {
     RaySoA in;
     const uint32_t* in_count; // device count for SRC_QUEUE
     uint32_t in_count_imm;    // count for SRC_RAYS
+    uint32_t min_waves;       // sparse levels: fewer rays per wave until this many waves are busy
     RaySoA out;
     uint32_t* out_count;
     float* direct;   // this level's direct-light colours, n_items * 3

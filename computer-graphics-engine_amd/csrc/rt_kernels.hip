@@ -28,7 +28,6 @@ constexpr int kBlock = 256; // 4 waves, one 8x8 pixel tile (or up to 64 queued r
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument: 128 VGPRs (31 dwords spilled), 4 waves per SIMD: +3 % (tools/ab.py)
 #endif
-constexpr uint32_t kMinWaves = 4096;      // aim for >= 4 busy waves per SIMD on sparse levels
 constexpr uint32_t kMinRaysPerWave = 4;
 
 RT_DEV V3 quat_rotate(const float* q, V3 v)
@@ -52,14 +51,18 @@ RT_DEV RayL camera_ray(const CameraArgs& c, int32_t x, int32_t y)
     return r;
 }
 
-// lane → pixel of an 8x8 tile; returns false for lanes outside the frame / row list
+// lane → pixel of the wave's tile (2^tile_wlog x 2^tile_hlog pixels; lanes past the
+// tile carry no ray and start as work thieves); false for lanes outside the frame /
+// row list. Small tiles spread a dense region over more waves: the frame time of a
+// centred object is the time of its heaviest tile.
 RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_t& x, int32_t& y, int32_t& lrow)
 {
-    const uint32_t tiles_x = (uint32_t)(c.width + 7) >> 3;
+    const uint32_t tw = 1u << c.tile_wlog, th = 1u << c.tile_hlog;
+    const uint32_t tiles_x = ((uint32_t)c.width + tw - 1u) >> c.tile_wlog;
     const uint32_t ty = wave / tiles_x, tx = wave - ty * tiles_x;
-    x = (int32_t)(tx * 8u + (lane & 7u));
-    lrow = (int32_t)(ty * 8u + (lane >> 3));
-    const bool ok = x < c.width && lrow < c.n_rows;
+    x = (int32_t)(tx * tw + (lane & (tw - 1u)));
+    lrow = (int32_t)(ty * th + (lane >> c.tile_wlog));
+    const bool ok = lane < tw * th && x < c.width && lrow < c.n_rows;
     y = 0;
     if (ok)
         y = c.rows ? c.rows[lrow] : c.row0 + lrow;
@@ -131,11 +134,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         const uint32_t count = a.source == SRC_QUEUE ? *a.in_count : a.in_count_imm;
         // Sparse levels: give each wave only R < 64 rays, so that the wave's other
         // lanes start idle and share those rays' trees by work stealing (rt_device.h).
-        // R is the largest power of two that still leaves >= kMinWaves busy waves,
+        // R is the largest power of two that still leaves >= min_waves busy waves,
         // raised again if the grid would not cover the queue.
         const uint32_t n_waves = gridDim.x * (kBlock / 64);
         uint32_t R = 64u;
-        while (R > kMinRaysPerWave && (count + R - 1u) / R < kMinWaves)
+        while (R > kMinRaysPerWave && (count + R - 1u) / R < a.min_waves)
             R >>= 1;
         while ((uint64_t)R * n_waves < count)
             R <<= 1;
@@ -465,7 +468,8 @@ uint32_t grid_for_waves(uint64_t waves) { return (uint32_t)((waves + (kBlock / 6
 
 uint64_t camera_waves(const CameraArgs& c)
 {
-    return (uint64_t)((c.width + 7) / 8) * (uint64_t)((c.n_rows + 7) / 8);
+    const uint32_t tw = 1u << c.tile_wlog, th = 1u << c.tile_hlog;
+    return (uint64_t)((c.width + tw - 1) / tw) * (uint64_t)((c.n_rows + th - 1) / th);
 }
 
 } // namespace

@@ -75,7 +75,11 @@ RT_DEV void leaf_fetch(const WaveLds& L, const float4* __restrict__ chunks, uint
     s.cmax = c_lo > c_hi ? c_lo : c_hi;
     s.live = sub < s.cnt;
     if (s.live)
+#ifdef RT_TWO_STAGE
+        s.c[0] = chunks[((size_t)s.ref + sub) * 6u]; // stage 1: plane only (n, D)
+#else
         load_chunks(chunks, s.ref, cnt_all, sub, s.c);
+#endif
     s.cnt = s.cnt ? cnt_all : 0u;
 }
 
@@ -106,6 +110,42 @@ RT_DEV void leaf_test_one(WaveLds& L, const float4 c[6], uint32_t r, uint32_t in
         atomicMin(&L.best[r], make_key(tt, index, sphere));
 }
 
+#ifdef RT_TWO_STAGE
+// Stage 2 only for lanes whose plane distance can still win: 0 <= t <= limit.
+template <bool COUNT>
+RT_DEV void leaf_test_two_stage(WaveLds& L, const float4* __restrict__ chunks, float4 c0, uint32_t r, uint32_t index,
+    LaneCounters& lc)
+{
+    const float4 a = L.rayA[r], b = L.rayB[r];
+    RayL ray;
+    ray.o = mk(a.x, a.y, a.z);
+    ray.d = mk(a.w, b.x, b.y);
+    if (COUNT) {
+        lc.tri++;
+        lc.tri_fetch++;
+    }
+    const V3 n = mk(c0.x, c0.y, c0.z);
+    const float tt = (c0.w - dot(ray.o, n)) / dot(ray.d, n);
+    const float lim = ray_limit(L, r);
+    // spheres (NaN-free D = radius, n = 0 → tt = inf or NaN) always go to stage 2
+    const bool maybe = (tt >= 0.0f && lim >= tt) || !(n.x != 0.0f || n.y != 0.0f || n.z != 0.0f);
+    if (maybe) {
+        float4 c[6];
+        c[0] = c0;
+        const float4* base = chunks + (size_t)index * 6u;
+#pragma unroll
+        for (int k = 1; k < 6; k++)
+            c[k] = base[k];
+        const PrimRecord rec = record_from_chunks(c);
+        const bool sphere = (rec.kind_mat & 0x80000000u) != 0u;
+        float t2;
+        const bool cand = sphere ? sphere_candidate(rec, ray, b.z, t2) : tri_candidate(rec, ray, b.z, t2);
+        if (cand)
+            atomicMin(&L.best[r], make_key(t2, index, sphere));
+    }
+}
+#endif
+
 // Entries [first, first + n) of the wave's leaf queue, n <= 64: two entries per
 // step, one per half-wave, one primitive per lane; the fetch of step k+1 is issued
 // before step k is tested.
@@ -130,7 +170,11 @@ RT_DEV void leaf_phase(WaveLds& L, const float4* __restrict__ chunks, uint32_t f
         if (k + 2 < n)
             leaf_fetch<ANY>(L, chunks, my_ref, my_rc, my_lb, prune, k + 2, n, upper, sub, nxt);
         if (cur.live)
+#ifdef RT_TWO_STAGE
+            leaf_test_two_stage<COUNT>(L, chunks, cur.c[0], cur.r, cur.ref + sub, lc);
+#else
             leaf_test_one<COUNT>(L, cur.c, cur.r, cur.ref + sub, lc);
+#endif
         // leaves larger than 32 primitives (brute-force mode, very large meshes)
         for (uint32_t base = 32u; base < cur.cmax; base += 32u) {
             const uint32_t idx = base + sub;
@@ -158,6 +202,9 @@ struct Walk {
     RayL cur;
     RayInv cur_inv;
     uint32_t cur_r;
+#ifdef RT_STAMPS
+    unsigned long long st_node = 0, st_leaf = 0, st_steal = 0, n_node = 0, n_leaf = 0;
+#endif
 
     RT_DEV void load_ray(uint32_t r)
     {
@@ -190,6 +237,9 @@ struct Walk {
     RT_DEV void flush_leaves(uint32_t threshold)
     {
         if (lq_n >= threshold && lq_n > 0u) {
+#ifdef RT_STAMPS
+            const unsigned long long ts = clock64();
+#endif
             wave_lds_fence();
             while (lq_n > 0u) {
                 const uint32_t n = lq_n < 64u ? lq_n : 64u;
@@ -197,6 +247,9 @@ struct Walk {
                 leaf_phase<ANY, COUNT>(L, chunks, lq_n, n, lane, prune, lc);
             }
             wave_lds_fence();
+#ifdef RT_STAMPS
+            st_leaf += clock64() - ts, n_leaf++;
+#endif
         }
     }
 
@@ -232,6 +285,9 @@ struct Walk {
             const uint64_t busy = ballot(sp > bot);
             if (busy == 0)
                 break;
+#ifdef RT_STAMPS
+            const unsigned long long ts0 = clock64();
+#endif
             if (busy != ~0ull) { // steal: idle lanes take the oldest entry of lanes holding >= 2
                 const bool donor = sp - bot >= 2u;
                 const uint64_t donors = ballot(donor);
@@ -260,6 +316,10 @@ struct Walk {
                     wave_lds_fence();
                 }
             }
+#ifdef RT_STAMPS
+            const unsigned long long ts1 = clock64();
+            st_steal += ts1 - ts0;
+#endif
             bool leaf_l = false, leaf_r = false;
             uint32_t l_ref = 0, l_cnt = 0, r_ref = 0, r_cnt = 0, r = 0;
             float lb_l = 0.0f, lb_r = 0.0f;
@@ -278,6 +338,14 @@ struct Walk {
                     const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
                     const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
                     const uint4 q3 = *reinterpret_cast<const uint4*>(&np->l_ref);
+#ifdef RT_DIAG_DOUBLE_LOADS // diagnostic: 4 more L1 accesses per visit, same lines, results unused
+                    {
+                        const volatile float4* vp = reinterpret_cast<const volatile float4*>(np);
+                        float4 d0, d1, d2, d3;
+                        d0.x = vp[0].x, d1.x = vp[1].x, d2.x = vp[2].x, d3.x = vp[3].x;
+                        asm volatile("" ::"v"(d0.x), "v"(d1.x), "v"(d2.x), "v"(d3.x));
+                    }
+#endif
                     const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
                     const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
                     bool hl, hr;
@@ -304,6 +372,9 @@ struct Walk {
             }
             queue_leaves(leaf_l, r, l_ref, l_cnt, lb_l);
             queue_leaves(leaf_r, r, r_ref, r_cnt, lb_r);
+#ifdef RT_STAMPS
+            st_node += clock64() - ts1, n_node++;
+#endif
             flush_leaves(sv.leaf_flush);
         }
     }
@@ -333,6 +404,9 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     L.best[lane] = kNoHit;
     Walk<ANY, COUNT> w { sv, L, use_bvh ? sv.chunks : sv.chunks_flat, lc, lane, prune, 0u, ray,
         make_ray_inv(ray, sv.extent), lane };
+#ifdef RT_STAMPS
+    const unsigned long long stamp_begin = clock64();
+#endif
 
     if (!use_bvh || sv.root_cnt != 0u) // the root is a leaf / brute force: one pair per ray
         w.queue_leaves(active, lane, use_bvh ? sv.root_ref : 0u, use_bvh ? sv.root_cnt : sv.n_prims, 0.0f);
@@ -354,6 +428,20 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
         }
     }
     wave_lds_fence(); // the caller may reuse L for the next query
+#ifdef RT_STAMPS
+    if (sv.stamps && lane == 0) {
+        const unsigned long long total = clock64() - stamp_begin;
+        const int base = ANY ? 8 : 0;
+        atomicAdd(&sv.stamps[base + 0], w.st_steal);
+        atomicAdd(&sv.stamps[base + 1], w.st_node);
+        atomicAdd(&sv.stamps[base + 2], w.st_leaf);
+        atomicAdd(&sv.stamps[base + 3], total);
+        atomicAdd(&sv.stamps[base + 4], w.n_node);
+        atomicAdd(&sv.stamps[base + 5], w.n_leaf);
+        atomicAdd(&sv.stamps[base + 6], 1ull);
+        atomicMax(&sv.stamps[base + 7], total);
+    }
+#endif
 }
 
 } // namespace rt

@@ -11,8 +11,21 @@ capi = importlib.import_module("computer-graphics-engine_amd.capi")
 scenes = importlib.import_module("computer-graphics-engine_amd.scenes")
 sharding = importlib.import_module("computer-graphics-engine_amd.sharding")
 
-name = sys.argv[1]
-values = [int(v) for v in sys.argv[2:]]
+# either "name v1 v2 ..." or combos "a=1,b=2 a=3,b=4 ..."
+if "=" in sys.argv[1]:
+    name = "combo"
+    values = sys.argv[1:]
+else:
+    name = sys.argv[1]
+    values = [int(v) for v in sys.argv[2:]]
+
+def apply(v):
+    if name == "combo":
+        for kv in v.split(","):
+            k, x = kv.split("=")
+            rt.set_option(k, int(x))
+    else:
+        rt.set_option(name, v)
 workload = "C3"
 rt = capi.Library()
 cfg = scenes.CONFIGS[workload]
@@ -26,7 +39,7 @@ res = {v: [] for v in values}
 cnts = {}
 for rnd in range(4):
     for v in values:
-        rt.set_option(name, v)
+        apply(v)
         if rnd == 0:
             c = R.count_rays(stream)
             cnts[v] = c
@@ -40,4 +53,4 @@ for rnd in range(4):
         res[v].append((time.perf_counter() - t0) / 20 * 1e3)
 for v in values:
     c = cnts[v]
-    print(f"{name}={v:3d}  ms/frame median {np.median(res[v]):.3f} min {min(res[v]):.3f}  box {c['box_tests']/1e6:.1f}M tri {c['tri_tests']/1e6:.1f}M rays {c['rays']}")
+    print(f"{name}={v!s:>28}  ms/frame median {np.median(res[v]):.3f} min {min(res[v]):.3f}  box {c['box_tests']/1e6:.1f}M tri {c['tri_tests']/1e6:.1f}M rays {c['rays']}")
