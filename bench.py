@@ -73,12 +73,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # Rehearsal on a one-GPU box only (never a reported number): BENCH_REHEARSAL=1 puts every
+    # rank on cuda:0 and lets gloo carry the exchange, to exercise the N > 1 code path.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     capi = importlib.import_module("computer-graphics-engine_amd.capi")
     scenes = importlib.import_module("computer-graphics-engine_amd.scenes")
@@ -126,6 +134,7 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         renderer.step(stream)
+    renderer.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -176,7 +185,8 @@ def main():
                        "rays_reflect": total["rays_reflect"], "box_tests": total["box_tests"],
                        "tri_tests": total["tri_tests"], "node_fetches": total["node_fetches"],
                        "tri_fetches": total["tri_fetches"], "algorithmic_bytes_per_frame": ab["frame"],
-                       "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather" if world > 1 else ""),
+                       "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather(overlapped)" if world > 1 else "")
+                       + ("+REHEARSAL-gloo-one-device" if rehearsal else ""),
                        "device": devname, "bvh_build_s": round(build_s, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -219,6 +219,8 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
     const uint32_t n = scene.n_prims();
     if (n == 0)
         return "empty scene (the reference throws bad_optional_access, bvh.cpp:132)";
+    if (n >= (1u << 26))
+        return "more than 2^26 primitives: a leaf count no longer fits the leaf-queue entry (rt_device.h)";
     Builder b;
     b.out = this;
     b.sah = sah_binning;
@@ -341,6 +343,10 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
     child_ref(root, root_ref, root_cnt);
     if (pairs.empty())
         pairs.emplace_back(); // keep the device array non-empty
+    // MAX_DEPTH = 16 caps a tree at 2^15 - 1 internal nodes; the traversal's packed deque
+    // entry (rt_device.h pack_entry) relies on it
+    if (pairs.size() > (1u << 15))
+        return "internal error: more than 32768 internal nodes";
     return "";
 }
 

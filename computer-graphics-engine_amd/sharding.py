@@ -10,10 +10,14 @@ and rt_deinterleave_strips writes the reference's row-flipped frame. The
 area-light RNG is keyed by the global pixel id, so the image does not depend on
 the number of ranks. torch.distributed is plumbing here (backend "nccl" = RCCL
 on ROCm; "gloo" in the CPU tests of the partition logic).
+
+Overlap: the exchange of frame k runs on a second HIP stream while frame k+1
+renders (two packed/gathered buffer pairs), so a sequence of frames costs
+max(render, exchange) per frame instead of their sum.
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 
@@ -59,10 +63,12 @@ def gather_strips(gathered, local):
 
 
 class StripRenderer:
-    """One rank's share of a frame + the gather. `step()` enqueues everything on
-    the given HIP stream without host synchronisation."""
+    """One rank's share of a frame + the gather. `step()` enqueues a whole frame
+    without host synchronisation; `frame` holds the newest assembled frame once the
+    device is synchronised (`finish()`)."""
 
-    def __init__(self, rt, bvh, cam, features, params, width, height, rank=0, world=1, strip_rows=8):
+    def __init__(self, rt, bvh, cam, features, params, width, height, rank=0, world=1, strip_rows=8,
+                 overlap=True):
         import torch
 
         self.rt, self.bvh, self.cam, self.f, self.p = rt, bvh, cam, features, params
@@ -70,21 +76,54 @@ class StripRenderer:
         self.rows = strip_rows_of_rank(height, strip_rows, rank, world)
         self.frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
         self.counters = torch.zeros(16, dtype=torch.int64, device="cuda")
+        self.overlap = overlap and world > 1
+        self.k = 0
         if world > 1:
             rmax = rows_max(height, strip_rows, world)
-            self.local = torch.zeros((rmax, width, 3), dtype=torch.float32, device="cuda")
-            self.gathered = torch.zeros((world, rmax, width, 3), dtype=torch.float32, device="cuda")
+            nbuf = 2 if self.overlap else 1
+            self.local = [torch.zeros((rmax, width, 3), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+            self.gathered = [torch.zeros((world, rmax, width, 3), dtype=torch.float32, device="cuda")
+                             for _ in range(nbuf)]
+            if self.overlap:
+                self.comm_stream = torch.cuda.Stream()
+                self.rendered = [torch.cuda.Event() for _ in range(nbuf)]   # buffer i holds a finished render
+                self.consumed = [torch.cuda.Event() for _ in range(nbuf)]   # buffer i's exchange has read it
+                self.used = [False] * nbuf
 
     def step(self, stream: int = 0):
+        """Render this rank's strips of one frame on `stream` (a raw hipStream_t, the
+        current torch stream) and exchange them."""
+        import torch
+
         if self.world == 1:
             self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
                                   stream=stream)
             return
-        self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local.data_ptr(),
+        i = self.k % len(self.local)
+        self.k += 1
+        cur = torch.cuda.current_stream()
+        if self.overlap and self.used[i]:
+            cur.wait_event(self.consumed[i])  # the exchange two frames ago must have read this buffer
+        self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local[i].data_ptr(),
                               rows=self.rows, packed=True, stream=stream)
-        gather_strips(self.gathered, self.local)
-        self.rt.deinterleave_strips(self.gathered.data_ptr(), self.frame.data_ptr(), self.W, self.H,
-                                    self.strip_rows, self.world, stream=stream)
+        if not self.overlap:
+            gather_strips(self.gathered[i], self.local[i])
+            self.rt.deinterleave_strips(self.gathered[i].data_ptr(), self.frame.data_ptr(), self.W, self.H,
+                                        self.strip_rows, self.world, stream=stream)
+            return
+        self.rendered[i].record(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.rendered[i])
+            gather_strips(self.gathered[i], self.local[i])
+            self.rt.deinterleave_strips(self.gathered[i].data_ptr(), self.frame.data_ptr(), self.W, self.H,
+                                        self.strip_rows, self.world, stream=self.comm_stream.cuda_stream)
+            self.consumed[i].record(self.comm_stream)
+        self.used[i] = True
+
+    def finish(self):
+        import torch
+
+        torch.cuda.synchronize()
 
     def count_rays(self, stream: int = 0) -> dict:
         """One untimed frame of this rank's rows with the counting kernels."""
@@ -96,7 +135,7 @@ class StripRenderer:
             self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
                                   counters_ptr=self.counters.data_ptr(), stream=stream)
         else:
-            self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local.data_ptr(),
+            self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local[0].data_ptr(),
                                   rows=self.rows, packed=True, counters_ptr=self.counters.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         vals = self.counters.cpu().numpy().view(np.uint64)

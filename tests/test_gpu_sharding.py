@@ -29,8 +29,9 @@ def _rank(rank, world, port, out_dir, width, height):
     cam = rt.camera(*scenes.default_camera_args(width, height))
     st = torch.cuda.current_stream().cuda_stream
     r = sharding.StripRenderer(rt, bvh, cam, f, p, width, height, rank, world)
-    r.step(st)
-    torch.cuda.synchronize()
+    for _ in range(5):                      # several frames: exercises the double-buffered exchange
+        r.step(st)
+    r.finish()
     cnt = r.count_rays(st)
     np.save(os.path.join(out_dir, f"frame_{rank}.npy"), r.frame.cpu().numpy())
     np.save(os.path.join(out_dir, f"rays_{rank}.npy"), np.array([cnt["rays"]], np.int64))
