@@ -25,7 +25,8 @@ EXPORTS = [
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips",
-    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check", "rt_set_option",
+    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
+    "rt_loaded_scene_destroy", "rt_io_last_error",
 ]
 
 
@@ -141,6 +142,11 @@ class Library:
         c.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
         c.rt_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         c.rt_set_option.argtypes = [C.c_char_p, C.c_int]
+        c.rt_io_last_error.restype = C.c_char_p
+        c.rt_load_obj.argtypes = [C.c_char_p, C.c_int, C.POINTER(abi.LightDesc), C.c_uint32, C.POINTER(C.c_void_p)]
+        c.rt_load_preset.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        c.rt_loaded_scene_desc.argtypes = [C.c_void_p, C.POINTER(abi.SceneDesc)]
+        c.rt_loaded_scene_destroy.argtypes = [C.c_void_p]
         c.rt_debug_div_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]
         c.rt_rand31.restype = C.c_uint32
@@ -156,6 +162,49 @@ class Library:
         buf = C.create_string_buffer(256)
         self._check(self.c.rt_device_info(C.byref(n), buf, 256))
         return n.value, buf.value.decode()
+
+    # -- scene ingestion (host only)
+    def _loaded_to_scene_data(self, handle, name) -> abi.SceneData:
+        desc = abi.SceneDesc()
+        if self.c.rt_loaded_scene_desc(handle, C.byref(desc)) != abi.RT_OK:
+            raise RtError(abi.RT_ERR_INVALID, (self.c.rt_io_last_error() or b"").decode())
+        scene = abi.SceneData(name=name)
+        for i in range(desc.n_meshes):
+            m = desc.meshes[i]
+            nv, nt = m.n_vertices, m.n_triangles
+            scene.meshes.append(abi.MeshData(
+                np.ctypeslib.as_array(m.positions, (nv, 3)).copy(), np.ctypeslib.as_array(m.normals, (nv, 3)).copy(),
+                np.ctypeslib.as_array(m.texcoords, (nv, 2)).copy(), np.ctypeslib.as_array(m.triangles, (nt, 3)).copy(),
+                abi.MaterialData(tuple(m.material.kd), tuple(m.material.ks), m.material.shininess,
+                                 m.material.transparency, m.material.texture)))
+        for i in range(desc.n_spheres):
+            s = desc.spheres[i]
+            scene.spheres.append(abi.SphereData(list(s.center), s.radius, abi.MaterialData(
+                tuple(s.material.kd), tuple(s.material.ks), s.material.shininess, s.material.transparency)))
+        for i in range(desc.n_lights):
+            l = desc.lights[i]
+            scene.lights.append(abi.LightData(l.kind, np.array([list(l.v[k]) for k in range(7)], np.float32)))
+        for i in range(desc.n_textures):
+            t = desc.textures[i]
+            scene.textures.append(np.ctypeslib.as_array(t.pixels, (t.height, t.width, 3)).copy())
+        self.c.rt_loaded_scene_destroy(handle)
+        return scene
+
+    def load_preset(self, scene_type: int, data_dir: str, name: str = "") -> abi.SceneData:
+        """≙ loadScenePrebuilt (src/scene.cpp:5-92)."""
+        h = C.c_void_p()
+        if self.c.rt_load_preset(scene_type, str(data_dir).encode(), C.byref(h)) != abi.RT_OK:
+            raise RtError(abi.RT_ERR_INVALID, (self.c.rt_io_last_error() or b"").decode())
+        return self._loaded_to_scene_data(h, name)
+
+    def load_obj(self, path: str, center_and_normalize: bool = False, lights=()) -> abi.SceneData:
+        """≙ loadSceneFromFile / loadMesh (src/scene.cpp:94-103, framework/src/mesh.cpp:52-176)."""
+        h = C.c_void_p()
+        arr = abi.lights_to_c(lights)
+        if self.c.rt_load_obj(str(path).encode(), 1 if center_and_normalize else 0, arr, len(lights),
+                              C.byref(h)) != abi.RT_OK:
+            raise RtError(abi.RT_ERR_INVALID, (self.c.rt_io_last_error() or b"").decode())
+        return self._loaded_to_scene_data(h, Path(path).stem)
 
     def set_option(self, name: str, value: int):
         self._check(self.c.rt_set_option(name.encode(), int(value)))

@@ -261,6 +261,20 @@ int rt_trace_batch(const rt_bvh* bvh, const rt_ray* rays, uint32_t n_rays, const
 int rt_intersect_batch(const rt_bvh* bvh, rt_ray* rays, uint32_t n_rays, const rt_features* features,
                        rt_hit* hits, rt_counters* counters);
 
+/* -- Scene ingestion ≙ loadMesh / centerAndScaleToUnitMesh
+ *    (framework/src/mesh.cpp:52-176, tinyobjloader semantics), Image::Image
+ *    (framework/src/image.cpp:13-35, PNG → fp32 RGB) and the preset scenes /
+ *    loadSceneFromFile (src/scene.cpp:5-103). Host only (no GPU needed). The loaded
+ *    scene owns its arrays; rt_loaded_scene_desc fills a descriptor that points
+ *    into it (valid until rt_loaded_scene_destroy) and can go to rt_scene_create. */
+typedef struct rt_loaded_scene rt_loaded_scene;
+int rt_load_obj(const char* path, int center_and_normalize, const rt_light_desc* lights, uint32_t n_lights,
+                rt_loaded_scene** out);
+int rt_load_preset(int scene_type /* SceneType, src/scene.h:14-25 */, const char* data_dir, rt_loaded_scene** out);
+int rt_loaded_scene_desc(rt_loaded_scene* scene, rt_scene_desc* out);
+int rt_loaded_scene_destroy(rt_loaded_scene* scene);
+const char* rt_io_last_error(void);
+
 /* -- Instrumentation for the roofline figure (bench.py): when enabled on a bvh,
  *    every k_trace_level launch of later rt_render_device calls is bracketed by
  *    hipEvents recorded on the launch stream. rt_profile_read synchronises the
