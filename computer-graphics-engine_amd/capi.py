@@ -26,7 +26,7 @@ EXPORTS = [
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips",
     "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
-    "rt_loaded_scene_destroy", "rt_io_last_error",
+    "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp",
 ]
 
 
@@ -147,6 +147,7 @@ class Library:
         c.rt_load_preset.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
         c.rt_loaded_scene_desc.argtypes = [C.c_void_p, C.POINTER(abi.SceneDesc)]
         c.rt_loaded_scene_destroy.argtypes = [C.c_void_p]
+        c.rt_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         c.rt_debug_div_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]
         c.rt_rand31.restype = C.c_uint32
@@ -205,6 +206,12 @@ class Library:
                               C.byref(h)) != abi.RT_OK:
             raise RtError(abi.RT_ERR_INVALID, (self.c.rt_io_last_error() or b"").decode())
         return self._loaded_to_scene_data(h, Path(path).stem)
+
+    def write_bmp(self, path, frame: np.ndarray):
+        """≙ Screen::writeBitmapToFile (src/screen.cpp:49-60); frame = (H, W, 3) fp32, row-flipped."""
+        frame = np.ascontiguousarray(frame, np.float32)
+        if self.c.rt_write_bmp(str(path).encode(), frame.ctypes.data, frame.shape[1], frame.shape[0]) != abi.RT_OK:
+            raise RtError(abi.RT_ERR_INVALID, (self.c.rt_io_last_error() or b"").decode())
 
     def set_option(self, name: str, value: int):
         self._check(self.c.rt_set_option(name.encode(), int(value)))

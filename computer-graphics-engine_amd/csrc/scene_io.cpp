@@ -799,4 +799,44 @@ int rt_loaded_scene_destroy(rt_loaded_scene* sc)
     return RT_OK;
 }
 
+// ≙ Screen::writeBitmapToFile (src/screen.cpp:49-60): clamp to [0,1], u8vec4(vec4(c,1)*255)
+// (truncation; NaN → 0 like cvttss2si's low byte), then stb_image_write's 4-channel BMP:
+// 14-byte file header + 108-byte V4 header (BI_BITFIELDS, 32 bpp), rows bottom-up, B G R A.
+// `rgb` is the row-flipped W*H*3 frame of rt_render (row 0 = top of the image).
+int rt_write_bmp(const char* path, const float* rgb, int32_t width, int32_t height)
+{
+    if (!path || !rgb || width <= 0 || height <= 0)
+        return io_fail("rt_write_bmp: bad argument");
+    std::vector<uint8_t> out;
+    auto u16 = [&](uint32_t v) { out.push_back(v & 255), out.push_back((v >> 8) & 255); };
+    auto u32 = [&](uint32_t v) { u16(v & 0xffff), u16(v >> 16); };
+    out.push_back('B'), out.push_back('M');
+    u32(14 + 108 + (uint32_t)width * height * 4), u16(0), u16(0), u32(14 + 108);
+    u32(108), u32((uint32_t)width), u32((uint32_t)height), u16(1), u16(32), u32(3);
+    for (int i = 0; i < 5; i++)
+        u32(0);
+    u32(0xff0000), u32(0xff00), u32(0xff), u32(0xff000000u);
+    for (int i = 0; i < 13; i++)
+        u32(0);
+    auto to_u8 = [](float c) -> uint8_t {
+        const float lo = c < 0.0f ? 0.0f : c;   // glm::max(x, 0): (x < 0) ? 0 : x — NaN stays NaN
+        const float cl = 1.0f < lo ? 1.0f : lo; // glm::min(., 1): (1 < x) ? 1 : x
+        const float s = cl * 255.0f;
+        if (!(s > -2147483904.0f && s < 2147483648.0f))
+            return 0; // cvttss2si: 0x80000000 → low byte 0
+        return (uint8_t)(int32_t)s;
+    };
+    for (int32_t j = height - 1; j >= 0; j--)
+        for (int32_t i = 0; i < width; i++) {
+            const float* p = rgb + ((size_t)j * width + i) * 3;
+            out.push_back(to_u8(p[2])), out.push_back(to_u8(p[1])), out.push_back(to_u8(p[0])), out.push_back(255);
+        }
+    FILE* f = std::fopen(path, "wb");
+    if (!f)
+        return io_fail(std::string("rt_write_bmp: cannot open ") + path);
+    const size_t n = std::fwrite(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    return n == out.size() ? RT_OK : io_fail("rt_write_bmp: short write");
+}
+
 } // extern "C"

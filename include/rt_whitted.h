@@ -274,6 +274,9 @@ int rt_load_preset(int scene_type /* SceneType, src/scene.h:14-25 */, const char
 int rt_loaded_scene_desc(rt_loaded_scene* scene, rt_scene_desc* out);
 int rt_loaded_scene_destroy(rt_loaded_scene* scene);
 const char* rt_io_last_error(void);
+/* ≙ Screen::writeBitmapToFile (src/screen.cpp:49-60, row f2): the row-flipped fp32 frame
+ * of rt_render → stb_image_write's 32-bit V4 BMP (clamp, *255, truncate; NaN → 0). */
+int rt_write_bmp(const char* path, const float* rgb, int32_t width, int32_t height);
 
 /* -- Instrumentation for the roofline figure (bench.py): when enabled on a bvh,
  *    every k_trace_level launch of later rt_render_device calls is bracketed by

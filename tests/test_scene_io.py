@@ -195,3 +195,25 @@ def test_number_parser_quirks(lib, tmp_path):
         return np.float32(sign * (math.ldexp(m * 5.0 ** exp, exp) if exp else m))
     got = s.meshes[0].positions[:3, 0]
     assert np.array_equal(bits(got), bits(np.float32([tiny(v) for v in vals[:3]])))
+
+
+def test_bmp_export_layout(lib, tmp_path):
+    """rt_write_bmp ≙ Screen::writeBitmapToFile: stb_image_write's 4-channel BMP (14 + 108 byte
+    headers, BI_BITFIELDS, bottom-up BGRA) of clamp(c,0,1)*255 truncated; NaN → 0. (No reference
+    BMP exists in the tree and src/screen.cpp needs GL to build: byte layout restated from
+    stb_image_write.h:492-510 — parity unpinned by execution.)"""
+    W, H = 5, 3
+    frame = np.zeros((H, W, 3), np.float32)
+    frame[0, 0] = [1.0, 0.5, 0.25]
+    frame[0, 1] = [2.0, -1.0, np.nan]
+    frame[2, 4] = [0.999, 0.004, 1.0 / 255.0]
+    lib.write_bmp(tmp_path / "o.bmp", frame)
+    raw = (tmp_path / "o.bmp").read_bytes()
+    assert raw[:2] == b"BM" and len(raw) == 14 + 108 + W * H * 4
+    size, _, off, hdr, w, h, planes, bpp, comp = struct.unpack("<IIIIiiHHI", raw[2:34])
+    assert (size, off, hdr, w, h, planes, bpp, comp) == (len(raw), 122, 108, W, H, 1, 32, 3)
+    assert struct.unpack("<IIII", raw[54:70]) == (0xff0000, 0xff00, 0xff, 0xff000000)
+    px = np.frombuffer(raw, np.uint8, W * H * 4, 122).reshape(H, W, 4)[::-1]     # bottom-up → top-down
+    assert px[0, 0].tolist() == [63, 127, 255, 255]                              # B G R A, truncation
+    assert px[0, 1].tolist() == [0, 0, 255, 255]                                 # NaN → 0, clamps
+    assert px[2, 4].tolist() == [1, 1, 254, 255]
