@@ -726,16 +726,16 @@ int rt_debug_div_check(uint32_t seed, uint32_t mode, uint64_t n_samples, uint64_
     return RT_OK;
 }
 
-// Diagnostic (library built with -DRT_STAMPS): zero / read the 16 phase-clock slots.
+// Diagnostic (library built with -DRT_STAMPS): zero / read the 24 phase-clock slots.
 int rt_debug_stamps(int reset, unsigned long long* out16)
 {
     if (!g_stamps)
-        HIP_TRY(hipMalloc((void**)&g_stamps, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&g_stamps, 24 * sizeof(unsigned long long)));
     HIP_TRY(hipDeviceSynchronize());
     if (out16)
-        HIP_TRY(hipMemcpy(out16, g_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out16, g_stamps, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset)
-        HIP_TRY(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_stamps, 0, 24 * sizeof(unsigned long long)));
     return RT_OK;
 }
 

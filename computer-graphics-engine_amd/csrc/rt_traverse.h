@@ -204,6 +204,7 @@ struct Walk {
     uint32_t cur_r;
 #ifdef RT_STAMPS
     unsigned long long st_node = 0, st_leaf = 0, st_steal = 0, n_node = 0, n_leaf = 0;
+    unsigned long long st_pop = 0, st_load = 0, st_alu = 0, st_push = 0; // finer split of the node step
 #endif
 
     RT_DEV void load_ray(uint32_t r)
@@ -333,6 +334,11 @@ struct Walk {
                 const bool skip = ANY ? (L.best[r] != kNoHit) : (prune && e_lb > ray_limit(L, r));
                 if (!skip) {
                     load_ray(r);
+#ifdef RT_STAMPS
+                    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the pop and the ray reads are back
+                    const unsigned long long tp = clock64();
+                    st_pop += tp - ts1;
+#endif
                     const NodePair* np = sv.nodes + entry_node(e);
                     const float4 q0 = *reinterpret_cast<const float4*>(&np->l_lo[0]); // l_lo xyz, l_hi x
                     const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
@@ -349,7 +355,17 @@ struct Walk {
                     const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
                     const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
                     bool hl, hr;
+#ifdef RT_STAMPS
+                    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the node's four quads are back
+                    const unsigned long long tl = clock64();
+                    st_load += tl - tp;
+#endif
                     test_pair(llo, lhi, rlo, rhi, r, hl, hr, lb_l, lb_r);
+#ifdef RT_STAMPS
+                    asm volatile("" ::"v"(lb_l), "v"(lb_r));
+                    const unsigned long long ta = clock64();
+                    st_alu += ta - tl;
+#endif
                     l_ref = q3.x, l_cnt = q3.y, r_ref = q3.z, r_cnt = q3.w;
                     const bool push_l = hl && l_cnt == 0u, push_r = hr && r_cnt == 0u;
                     // the nearer child goes on top (popped first): finds close hits early
@@ -368,6 +384,9 @@ struct Walk {
                     }
                     leaf_l = hl && l_cnt != 0u;
                     leaf_r = hr && r_cnt != 0u;
+#ifdef RT_STAMPS
+                    st_push += clock64() - ta;
+#endif
                 }
             }
             queue_leaves(leaf_l, r, l_ref, l_cnt, lb_l);
@@ -440,6 +459,12 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
         atomicAdd(&sv.stamps[base + 5], w.n_leaf);
         atomicAdd(&sv.stamps[base + 6], 1ull);
         atomicMax(&sv.stamps[base + 7], total);
+        if (!ANY) {
+            atomicAdd(&sv.stamps[16], w.st_pop);
+            atomicAdd(&sv.stamps[17], w.st_load);
+            atomicAdd(&sv.stamps[18], w.st_alu);
+            atomicAdd(&sv.stamps[19], w.st_push);
+        }
     }
 #endif
 }

@@ -23,7 +23,7 @@ rt.c.rt_debug_stamps(1, None)
 R.step(st); torch.cuda.synchronize()
 rt.c.rt_debug_stamps(1, None)
 R.step(st); torch.cuda.synchronize()
-out = np.zeros(16, np.uint64)
+out = np.zeros(24, np.uint64)
 rt.c.rt_debug_stamps(0, out.ctypes.data)
 for name, b in (("closest", 0), ("shadow", 8)):
     steal, node, leaf, total, n_node, n_leaf, waves, mx = [int(x) for x in out[b:b + 8]]
@@ -31,3 +31,9 @@ for name, b in (("closest", 0), ("shadow", 8)):
     print(f"{name}: waves {waves} total cycles {total/1e6:.1f}M  avg/wave {total/waves:.0f} max wave {mx}"
           f" | steal {steal/total:.1%} node {node/total:.1%} leaf {leaf/total:.1%} other {(total-steal-node-leaf)/total:.1%}"
           f" | node iters {n_node} ({node/max(n_node,1):.0f} cyc each) leaf flushes {n_leaf} ({leaf/max(n_leaf,1):.0f} cyc each)")
+
+pop, load, alu, push = [int(x) for x in out[16:20]]
+n_node = int(out[4])
+if n_node:
+    print(f"closest node step split (cycles per step, lane 0 of each wave): pop+ray {pop/n_node:.0f}  node gather {load/n_node:.0f}"
+          f"  slab tests {alu/n_node:.0f}  push {push/n_node:.0f}")
