@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 3 }, g_tile_hlog { 3 }, g_min_waves { 4096 };
+std::atomic<int> g_tile_wlog { 3 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -126,6 +126,11 @@ struct rt_bvh {
     rt::HostBvh host;
     DevBuf<rt::NodePair> nodes;
     DevBuf<rt::PrimRecord> prims, prims_flat;
+    DevBuf<rt::LeafRecord> leaf, leaf_flat;
+#ifdef RT_DIAG
+    DevBuf<rt::NodePair> diag_nodes;
+    DevBuf<rt::LeafRecord> diag_leaf;
+#endif
     std::mutex mu;
     bool profile = false;
     std::map<void*, std::unique_ptr<Scratch>> scratch; // keyed by stream
@@ -143,8 +148,8 @@ struct rt_bvh {
         v.nodes = nodes.p;
         v.prims = prims.p;
         v.prims_flat = prims_flat.p;
-        v.chunks = reinterpret_cast<const float4*>(prims.p);
-        v.chunks_flat = reinterpret_cast<const float4*>(prims_flat.p);
+        v.leaf = reinterpret_cast<const float4*>(leaf.p);
+        v.leaf_flat = reinterpret_cast<const float4*>(leaf_flat.p);
         v.tri_vidx = scene->tri_vidx.p;
         v.vnormal = scene->vnormal.p;
         v.vtexcoord = scene->vtexcoord.p;
@@ -160,6 +165,10 @@ struct rt_bvh {
         v.extent = scene->host.extent;
         v.leaf_flush = (uint32_t)g_leaf_flush.load();
         v.stamps = g_stamps;
+#ifdef RT_DIAG
+        v.diag_nodes = diag_nodes.p;
+        v.diag_leaf = reinterpret_cast<const float4*>(diag_leaf.p);
+#endif
         return v;
     }
 };
@@ -216,6 +225,22 @@ int check_params(const rt_render_params* p)
     return RT_OK;
 }
 
+// the leaf phase's 48-byte view of the primitive records (rt_layout.h)
+std::vector<rt::LeafRecord> leaf_records(const std::vector<rt::PrimRecord>& recs)
+{
+    std::vector<rt::LeafRecord> out(recs.size());
+    for (size_t i = 0; i < recs.size(); i++) {
+        const rt::PrimRecord& r = recs[i];
+        rt::LeafRecord& l = out[i];
+        memcpy(l.v0, r.v0, 12), memcpy(l.v1, r.v1, 12), memcpy(l.v2, r.v2, 12), memcpy(l.n, r.n, 12);
+        if (r.kind_mat & 0x80000000u) {
+            l.v1[0] = r.D; // radius
+            l.n[0] = l.n[1] = l.n[2] = 0.0f;
+        }
+    }
+    return out;
+}
+
 rt::CameraArgs camera_args(const rt_camera& c, int32_t w, int32_t h)
 {
     rt::CameraArgs a;
@@ -225,6 +250,7 @@ rt::CameraArgs camera_args(const rt_camera& c, int32_t w, int32_t h)
     a.width = w, a.height = h;
     a.rows = nullptr, a.row0 = 0, a.n_rows = h;
     a.tile_wlog = (uint32_t)g_tile_wlog.load(), a.tile_hlog = (uint32_t)g_tile_hlog.load();
+    a.super_log = (uint32_t)g_super_log.load();
     return a;
 }
 
@@ -363,6 +389,12 @@ int rt_set_option(const char* name, int value)
         (name[5] == 'w' ? g_tile_wlog : g_tile_hlog).store(value);
         return RT_OK;
     }
+    if (name && strcmp(name, "super_log") == 0) {
+        if (value < 0 || value > 6)
+            return fail(RT_ERR_INVALID, "rt_set_option: super_log must be in [0, 6]");
+        g_super_log.store(value);
+        return RT_OK;
+    }
     if (name && strcmp(name, "min_waves") == 0) {
         if (value < 1)
             return fail(RT_ERR_INVALID, "rt_set_option: min_waves must be >= 1");
@@ -447,6 +479,15 @@ int rt_bvh_build(rt_scene* scene, const rt_features* features, rt_bvh** out)
     HIP_TRY(b->nodes.upload(b->host.pairs));
     HIP_TRY(b->prims.upload(b->host.records));
     HIP_TRY(b->prims_flat.upload(b->host.records_flat));
+    HIP_TRY(b->leaf.upload(leaf_records(b->host.records)));
+    HIP_TRY(b->leaf_flat.upload(leaf_records(b->host.records_flat)));
+#ifdef RT_DIAG
+    HIP_TRY(b->diag_nodes.upload(b->host.pairs));
+    HIP_TRY(b->diag_leaf.upload(leaf_records(b->host.records)));
+#if RT_DIAG == 2
+    rt::set_diag_leaf(reinterpret_cast<const float4*>(b->diag_leaf.p));
+#endif
+#endif
     *out = b.release();
     return RT_OK;
 }

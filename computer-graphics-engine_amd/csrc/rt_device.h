@@ -105,7 +105,7 @@ struct LaneCounters {
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
 };
 
-// Per-wave LDS working set (8.4 KiB): ray table, best-key slots, the per-lane
+// Per-wave LDS working set (9.4 KiB): ray table, best-key slots, the per-lane
 // deques (slot [level][lane]: conflict-free; entry = node pair index << 6 | ray
 // slot, plus the entry's distance lower bound) and the (ray, leaf) pair queue.
 constexpr uint32_t kStackLevels = 16; // MAX_DEPTH = 16 levels ⇒ at most 15 internal levels pending
@@ -113,7 +113,8 @@ constexpr uint32_t kLeafFlushMax = 16; // largest leaf_flush threshold (SceneVie
 constexpr uint32_t kLeafQueue = 144;   // < kLeafFlushMax left over + at most 128 appended per node step
 struct alignas(16) WaveLds {
     float4 rayA[64]; // ox oy oz dx
-    float4 rayB[64]; // dy dz t0 -
+    float4 rayB[64]; // dy dz t0 guard bits (RayInv::ok[0..2], all_ok)
+    float4 rayC[64]; // RN(1/dx) RN(1/dy) RN(1/dz) pruning slack — RayInv, computed once per ray
     unsigned long long best[64];
     uint32_t stack[kStackLevels][64]; // packed entries, see pack_entry()
     uint32_t lq_ref[kLeafQueue];
@@ -121,7 +122,7 @@ struct alignas(16) WaveLds {
     float lq_lb[kLeafQueue];
     uint32_t xfer[64];          // work-stealing hand-over slots
 };
-static_assert(sizeof(WaveLds) == 8640, "WaveLds"); // x4 waves = 33.75 KiB per block: 4 blocks per CU
+static_assert(sizeof(WaveLds) == 9664, "WaveLds"); // one wave per workgroup: 16 of them fit a CU's 160 KiB
 
 // A deque entry in 32 bits: [31:21] lower bound, [20:6] node pair index, [5:0] ray slot.
 // MAX_DEPTH = 16 levels caps a tree at 32 767 internal nodes (15 bits). The bound keeps
@@ -153,6 +154,7 @@ RT_DEV uint32_t entry_ray(uint32_t e) { return e & 63u; }
 struct RayInv {
     float y[3]; // RN(1 / d[a])
     bool ok[3];
+    bool all_ok; // ok on all three axes (then no component of d is zero either)
     float slack; // rho * max_a |1/d[a]|: how far a slab plane moved by rho shifts t (pruning bound)
 };
 // `extent` = largest |coordinate| of the scene (SceneView::extent).
@@ -173,6 +175,7 @@ RT_DEV RayInv make_ray_inv(const RayL& r, float extent)
     // rho (see "Pruning" below): 2^-16 of the largest coordinate magnitude in play
     const float S = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fmaxf(fabsf(r.o.z), extent));
     v.slack = (S * 1.52587890625e-05f) * ymax;
+    v.all_ok = v.ok[0] && v.ok[1] && v.ok[2];
     return v;
 }
 RT_DEV float div_by_ray(float n, float d, float y, bool ok)
@@ -204,9 +207,10 @@ RT_DEV float div_by_ray(float n, float d, float y, bool ok)
 // distance computed below (before the reference's "origin inside" rewrite).
 // Spheres are excluded (their test assumes |d| = 1): scenes with spheres do not
 // prune. Proven against the unpruned traversal in tests/test_gpu_parity.py.
-RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const RayInv& inv, float& lb)
+// the six slab quotients of one box, guarded division per quotient (any input)
+RT_DEV void slab_quotients(const float lo[3], const float hi[3], const RayL& r, const RayInv& inv, float tl[3],
+    float th[3])
 {
-    float tl[3], th[3];
     const float o[3] = { r.o.x, r.o.y, r.o.z };
     const float d[3] = { r.d.x, r.d.y, r.d.z };
 #pragma unroll
@@ -219,9 +223,14 @@ RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const R
             th[a] = div_by_ray(hi[a] - o[a], d[a], inv.y[a], inv.ok[a]);
         }
     }
+}
+
+// the reference's decision on the six quotients, and the pruning bound
+RT_DEV bool slab_decide(const float tl[3], const float th[3], float slack, float& lb)
+{
     float tin = sel_max(sel_min(th[2], tl[2]), sel_max(sel_min(th[1], tl[1]), sel_min(th[0], tl[0])));
     float tout = sel_min(sel_max(th[2], tl[2]), sel_min(sel_max(th[1], tl[1]), sel_max(th[0], tl[0])));
-    lb = tin * 0.99999904632568359375f - inv.slack; // (1 - 2^-20); negative or NaN never prunes
+    lb = tin * 0.99999904632568359375f - slack; // (1 - 2^-20); negative or NaN never prunes
     if (tin < 0.0f) {
         if (!(tout > 0.0f))
             return false;
@@ -231,6 +240,57 @@ RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const R
     if (tin > tout || tin < 0.0f || tin > kFltMax)
         return false;
     return true;
+}
+
+RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const RayInv& inv, float& lb)
+{
+    float tl[3], th[3];
+    slab_quotients(lo, hi, r, inv, tl, th);
+    return slab_decide(tl, th, inv.slack, lb);
+}
+
+// Both boxes of a node pair. The twelve quotients share ONE guard: when the ray's three
+// reciprocals are usable (all_ok) and every numerator's magnitude lies in
+// [2^-60, 2^61) — the same windows div_by_ray checks one by one — all twelve take the
+// three-instruction path without a branch each; otherwise (origin exactly on a slab
+// plane, an axis-parallel ray, extreme values) the pair falls back to the guarded
+// per-quotient code. Same results either way, ~half the instructions on the hot path.
+RT_DEV void box_pair_hit(const float llo[3], const float lhi[3], const float rlo[3], const float rhi[3],
+    const RayL& r, const RayInv& inv, bool& hl, bool& hr, float& lb_l, float& lb_r)
+{
+    const float o[3] = { r.o.x, r.o.y, r.o.z };
+    const float d[3] = { r.d.x, r.d.y, r.d.z };
+    float n[12];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        n[a] = llo[a] - o[a];
+        n[3 + a] = lhi[a] - o[a];
+        n[6 + a] = rlo[a] - o[a];
+        n[9 + a] = rhi[a] - o[a];
+    }
+    float amin = fabsf(n[0]), amax = fabsf(n[0]);
+#pragma unroll
+    for (int i = 1; i < 12; i++) {
+        amin = fminf(amin, fabsf(n[i])); // fminf / fmaxf skip a NaN numerator: it needs no guard,
+        amax = fmaxf(amax, fabsf(n[i])); // both paths turn it into a NaN quotient
+    }
+    float tl_l[3], th_l[3], tl_r[3], th_r[3];
+    if (inv.all_ok && amin >= 0x1p-60f && amax < 0x1p61f) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float y = inv.y[a], nd = -d[a];
+            float q;
+            q = n[a] * y, tl_l[a] = __builtin_fmaf(__builtin_fmaf(nd, q, n[a]), y, q);
+            q = n[3 + a] * y, th_l[a] = __builtin_fmaf(__builtin_fmaf(nd, q, n[3 + a]), y, q);
+            q = n[6 + a] * y, tl_r[a] = __builtin_fmaf(__builtin_fmaf(nd, q, n[6 + a]), y, q);
+            q = n[9 + a] * y, th_r[a] = __builtin_fmaf(__builtin_fmaf(nd, q, n[9 + a]), y, q);
+        }
+    } else {
+        slab_quotients(llo, lhi, r, inv, tl_l, th_l);
+        slab_quotients(rlo, rhi, r, inv, tl_r, th_r);
+    }
+    hl = slab_decide(tl_l, th_l, inv.slack, lb_l);
+    hr = slab_decide(tl_r, th_r, inv.slack, lb_r);
 }
 
 // A.2: t of the ray with the triangle's plane (n, D precomputed on the host with
@@ -260,11 +320,30 @@ RT_DEV bool tri_candidate(const PrimRecord& rec, const RayL& r, float t0, float&
     return true;
 }
 
-// A.3 intersectRayWithShape(Sphere): assumes |direction| = 1, strict t < ray.t
-RT_DEV bool sphere_candidate(const PrimRecord& rec, const RayL& r, float t0, float& tt)
+// The same test from the leaf phase's 48-byte record (v0, v1, v2, n): D and the edge
+// vectors are recomputed with the host's operation order (host_scene.cpp), so every
+// intermediate equals the PrimRecord field bit for bit.
+RT_DEV bool tri_candidate_leaf(V3 v0, V3 v1, V3 v2, V3 n, const RayL& r, float t0, float& tt)
 {
-    const V3 c = ld3(rec.v0);
-    const float radius = rec.D;
+    const float D = dot(v0, n);
+    tt = (D - dot(r.o, n)) / dot(r.d, n);
+    if (!(tt >= 0.0f))
+        return false;
+    if (!(t0 >= tt))
+        return false;
+    const V3 p = r.d * tt + r.o;
+    if (!(dot(cross(v2 - v0, n), p - v0) >= 0.0f))
+        return false;
+    if (!(dot(cross(v0 - v1, n), p - v1) >= 0.0f))
+        return false;
+    if (!(dot(cross(v1 - v2, n), p - v2) >= 0.0f))
+        return false;
+    return true;
+}
+
+// A.3 intersectRayWithShape(Sphere): assumes |direction| = 1, strict t < ray.t
+RT_DEV bool sphere_candidate(V3 c, float radius, const RayL& r, float t0, float& tt)
+{
     const V3 oc = r.o - c;
     const float h = dot(r.d, oc);
     const float B = h + h;
@@ -292,6 +371,11 @@ RT_DEV bool sphere_candidate(const PrimRecord& rec, const RayL& r, float t0, flo
     if (tt < 0.0f || tt >= t0)
         return false;
     return true;
+}
+
+RT_DEV bool sphere_candidate(const PrimRecord& rec, const RayL& r, float t0, float& tt)
+{
+    return sphere_candidate(ld3(rec.v0), rec.D, r, t0, tt);
 }
 
 // 64-bit reduction key: smaller = better. High word: t bits (t >= 0, so unsigned

@@ -26,6 +26,7 @@ struct CameraArgs {
     const int32_t* rows; // device list of image rows, NULL → row0 + local row
     int32_t row0, n_rows;
     uint32_t tile_wlog, tile_hlog; // primary tile = 2^wlog x 2^hlog pixels per wave (<= 64)
+    uint32_t super_log;            // > 0: super-tiles of 2^s x 2^s tiles dealt to the XCDs (tile_pixel)
 };
 
 // One recursion level of the flattened Whitted recursion (k_trace_level).
@@ -77,6 +78,9 @@ struct IntersectArgs {
 };
 
 extern uint32_t g_lds_pad;
+#if defined(RT_DIAG) && RT_DIAG == 2
+void set_diag_leaf(const float4* p);
+#endif
 void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s);
 void launch_fold(const FoldArgs& a, hipStream_t s);
 void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s);

@@ -24,7 +24,13 @@ namespace rt {
 
 namespace {
 
-constexpr int kBlock = 256; // 4 waves, one 8x8 pixel tile (or up to 64 queued rays) each
+#ifndef RT_BLOCK
+#define RT_BLOCK 64
+#endif
+// One wave per workgroup: waves share nothing, and a multi-wave workgroup keeps its LDS
+// (so its CU slot) until its slowest wave ends — with tiles as uneven as "knot" vs
+// "background" that left ~60 % of the wave slots empty (SQ_WAVE_CYCLES, profiles/r01_notes.md).
+constexpr int kBlock = RT_BLOCK;
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument: 128 VGPRs (31 dwords spilled), 4 waves per SIMD: +3 % (tools/ab.py)
 #endif
@@ -55,14 +61,32 @@ RT_DEV RayL camera_ray(const CameraArgs& c, int32_t x, int32_t y)
 // tile carry no ray and start as work thieves); false for lanes outside the frame /
 // row list. Small tiles spread a dense region over more waves: the frame time of a
 // centred object is the time of its heaviest tile.
+// Wave -> primary tile. With super_log = s > 0 the tiles are grouped into super-tiles
+// of 2^s x 2^s tiles and whole super-tiles are dealt round-robin to the 8 XCDs
+// (workgroup b runs on XCD b % 8): every XCD's L2 then serves the triangles behind
+// 1/8 of the screen instead of the whole visible scene. Purely a locality choice —
+// item / pixel indices do not depend on it.
 RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_t& x, int32_t& y, int32_t& lrow)
 {
     const uint32_t tw = 1u << c.tile_wlog, th = 1u << c.tile_hlog;
     const uint32_t tiles_x = ((uint32_t)c.width + tw - 1u) >> c.tile_wlog;
-    const uint32_t ty = wave / tiles_x, tx = wave - ty * tiles_x;
+    uint32_t tx, ty;
+    if (c.super_log == 0) {
+        ty = wave / tiles_x, tx = wave - ty * tiles_x;
+    } else {
+        const uint32_t s = c.super_log, wpb = kBlock / 64;
+        const uint32_t bpc = (1u << (2 * s)) / wpb; // workgroups per super-tile
+        const uint32_t b = wave / wpb, wi = wave - b * wpb;
+        const uint32_t xcd = b & 7u, j = b >> 3;
+        const uint32_t chunk = (j / bpc) * 8u + xcd, k = (j % bpc) * wpb + wi;
+        const uint32_t sx = (tiles_x + (1u << s) - 1u) >> s;
+        const uint32_t scy = chunk / sx, scx = chunk - scy * sx;
+        tx = (scx << s) + (k & ((1u << s) - 1u));
+        ty = (scy << s) + (k >> s);
+    }
     x = (int32_t)(tx * tw + (lane & (tw - 1u)));
     lrow = (int32_t)(ty * th + (lane >> c.tile_wlog));
-    const bool ok = lane < tw * th && x < c.width && lrow < c.n_rows;
+    const bool ok = lane < tw * th && tx < tiles_x && x < c.width && lrow < c.n_rows;
     y = 0;
     if (ok)
         y = c.rows ? c.rows[lrow] : c.row0 + lrow;
@@ -469,11 +493,19 @@ uint32_t grid_for_waves(uint64_t waves) { return (uint32_t)((waves + (kBlock / 6
 uint64_t camera_waves(const CameraArgs& c)
 {
     const uint32_t tw = 1u << c.tile_wlog, th = 1u << c.tile_hlog;
-    return (uint64_t)((c.width + tw - 1) / tw) * (uint64_t)((c.n_rows + th - 1) / th);
+    const uint64_t tiles_x = (c.width + tw - 1) / tw, tiles_y = (c.n_rows + th - 1) / th;
+    if (c.super_log == 0)
+        return tiles_x * tiles_y;
+    const uint32_t s = c.super_log;
+    const uint64_t chunks = ((tiles_x + (1u << s) - 1) >> s) * ((tiles_y + (1u << s) - 1) >> s);
+    return ((chunks + 7) / 8 * 8) << (2 * s); // whole super-tiles, a multiple of 8 of them (tile_pixel)
 }
 
 } // namespace
 
+#if defined(RT_DIAG) && RT_DIAG == 2
+void set_diag_leaf(const float4* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_leaf), &p, sizeof(p)); }
+#endif
 uint32_t g_lds_pad = 0; // tuning experiment: extra dynamic LDS per block lowers occupancy
 
 void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)

@@ -51,6 +51,19 @@ struct alignas(32) PrimRecord {
 };
 static_assert(sizeof(PrimRecord) == 96, "PrimRecord must be 96 bytes");
 
+// What the LEAF phase loads per primitive tested: 48 bytes = three 16-byte words
+// (measured on MI355X, tools/ta_bench.hip: a wave's loads cost per byte and per line
+// touched, and a 96-byte stride costs twice a 48-byte one, so the record holds only
+// what cannot be recomputed cheaply). D and the edge vectors e0..e2 are recomputed per
+// test from (v0, v1, v2, n) with the host's operation order, so they are bit-identical
+// to the PrimRecord fields. A sphere is tagged by n == (0, 0, 0) — a triangle's normal
+// is unit length, or NaN/inf when degenerate, never all zero — with v0 = centre,
+// v1[0] = radius.
+struct alignas(16) LeafRecord {
+    float v0[3], v1[3], v2[3], n[3];
+};
+static_assert(sizeof(LeafRecord) == 48, "LeafRecord must be 48 bytes");
+
 // Material slot (framework mesh.h:22-34 without the shared_ptr)
 struct alignas(16) MaterialRec {
     float kd[3];
@@ -80,9 +93,9 @@ struct SceneView {
     const NodePair* nodes;
     const PrimRecord* prims;      // BVH mode: the reference's visit order (right-first DFS over the leaves)
     const PrimRecord* prims_flat; // brute-force mode (enableAccelStructure off): the reference's array order
-    // the same two arrays viewed as six 16-byte words per record (leaf-phase loads)
-    const float4* chunks;
-    const float4* chunks_flat;
+    // LeafRecord arrays in the same two orders, as three 16-byte words per primitive
+    const float4* leaf;
+    const float4* leaf_flat;
     const uint32_t* tri_vidx;   // prim_id*3 → global vertex index (triangles only)
     const float* vnormal;       // global vertex normals, xyz
     const float* vtexcoord;     // global vertex texcoords, uv
@@ -96,6 +109,10 @@ struct SceneView {
     uint32_t prune_ok; // 0 when the scene holds spheres (rt_device.h: Pruning)
     float extent;      // largest |coordinate| of any vertex
     unsigned long long* stamps; // diagnostic builds (-DRT_STAMPS) only, else NULL
+#ifdef RT_DIAG // diagnostic builds: second copies at other addresses (tools/diag.sh)
+    const NodePair* diag_nodes;
+    const float4* diag_leaf;
+#endif
     uint32_t leaf_flush; // leaf-queue fill at which the wave switches to the leaf phase (tuning, 2..64)
 };
 

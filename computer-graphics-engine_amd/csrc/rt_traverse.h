@@ -14,47 +14,34 @@
 //    819 200-triangle bench scene it is 2.5x slower — its visits form one serial
 //    chain per wave — and was dropped; profiles/r01_notes.md.)
 //  LEAF phase. Leaf children are parked as (ray, leaf) pairs in a per-wave queue;
-//    half a wave tests one pair, one primitive per lane (six 16-byte loads of its
-//    96-byte record), the next pair's records are prefetched.
+//    half a wave tests one pair, one primitive per lane (three 16-byte loads of its
+//    48-byte LeafRecord), the next pair's records are prefetched.
 #pragma once
 #include "rt_device.h"
 
 namespace rt {
 
 // ---- leaf phase -----------------------------------------------------------------
+#if defined(RT_DIAG) && RT_DIAG == 2
+__device__ const float4* g_diag_leaf;
+#endif
 struct LeafSlot {
-    float4 c[6];                // the primitive's record, chunk by chunk
+    float4 c[3];                // the primitive's LeafRecord, 16 bytes at a time
     uint32_t r, ref, cnt, cmax; // ray slot, first primitive, this half's count, max of both halves
     bool live;                  // this lane holds a record of the first 32 primitives
 };
 
-RT_DEV PrimRecord record_from_chunks(const float4 c[6])
+// the three 16-byte words of primitive (ref + i)
+RT_DEV void load_leaf(const float4* __restrict__ leaf, uint32_t ref, uint32_t i, float4 c[3])
 {
-    PrimRecord rec;
-    rec.n[0] = c[0].x, rec.n[1] = c[0].y, rec.n[2] = c[0].z, rec.D = c[0].w;
-    rec.e0[0] = c[1].x, rec.e0[1] = c[1].y, rec.e0[2] = c[1].z, rec.e1[0] = c[1].w;
-    rec.e1[1] = c[2].x, rec.e1[2] = c[2].y, rec.e2[0] = c[2].z, rec.e2[1] = c[2].w;
-    rec.e2[2] = c[3].x, rec.v0[0] = c[3].y, rec.v0[1] = c[3].z, rec.v0[2] = c[3].w;
-    rec.v1[0] = c[4].x, rec.v1[1] = c[4].y, rec.v1[2] = c[4].z, rec.v2[0] = c[4].w;
-    rec.v2[1] = c[5].x, rec.v2[2] = c[5].y;
-    rec.prim_id = (int32_t)__float_as_uint(c[5].z);
-    rec.kind_mat = __float_as_uint(c[5].w);
-    return rec;
-}
-
-// the six 16-byte words of primitive (ref + i). (A chunk-major per-leaf layout that
-// makes these loads contiguous across lanes was measured 11 % SLOWER than the plain
-// 96-byte records — the phase is latency-, not transaction-bound — and dropped.)
-RT_DEV void load_chunks(const float4* __restrict__ chunks, uint32_t ref, uint32_t /*cnt*/, uint32_t i, float4 c[6])
-{
-    const float4* base = chunks + ((size_t)ref + i) * 6u;
+    const float4* base = leaf + ((size_t)ref + i) * 3u;
 #pragma unroll
-    for (int k = 0; k < 6; k++)
+    for (int k = 0; k < 3; k++)
         c[k] = base[k];
 }
 
 template <bool ANY>
-RT_DEV void leaf_fetch(const WaveLds& L, const float4* __restrict__ chunks, uint32_t my_ref, uint32_t my_rc,
+RT_DEV void leaf_fetch(const WaveLds& L, const float4* __restrict__ leaf, uint32_t my_ref, uint32_t my_rc,
     float my_lb, bool prune, uint32_t k, uint32_t n, bool upper, uint32_t sub, LeafSlot& s)
 {
     const uint32_t ref0 = read_lane(my_ref, k), rc0 = read_lane(my_rc, k);
@@ -75,32 +62,37 @@ RT_DEV void leaf_fetch(const WaveLds& L, const float4* __restrict__ chunks, uint
     s.cmax = c_lo > c_hi ? c_lo : c_hi;
     s.live = sub < s.cnt;
     if (s.live)
-#ifdef RT_TWO_STAGE
-        s.c[0] = chunks[((size_t)s.ref + sub) * 6u]; // stage 1: plane only (n, D)
-#else
-        load_chunks(chunks, s.ref, cnt_all, sub, s.c);
+        load_leaf(leaf, s.ref, sub, s.c);
+#if defined(RT_DIAG) && RT_DIAG == 2 // the same three loads from a second copy of the leaf array
+    if (s.live) {
+        float4 d[3];
+        load_leaf(g_diag_leaf, s.ref, sub, d);
+        asm volatile("" ::"v"(d[0].x), "v"(d[1].y), "v"(d[2].z));
+    }
 #endif
     s.cnt = s.cnt ? cnt_all : 0u;
 }
 
 template <bool COUNT>
-RT_DEV void leaf_test_one(WaveLds& L, const float4 c[6], uint32_t r, uint32_t index, LaneCounters& lc)
+RT_DEV void leaf_test_one(WaveLds& L, const float4 c[3], uint32_t r, uint32_t index, bool spheres, LaneCounters& lc)
 {
-    const PrimRecord rec = record_from_chunks(c);
     const float4 a = L.rayA[r], b = L.rayB[r];
     RayL ray;
     ray.o = mk(a.x, a.y, a.z);
     ray.d = mk(a.w, b.x, b.y);
     const float t0 = b.z;
+    const V3 v0 = mk(c[0].x, c[0].y, c[0].z), v1 = mk(c[0].w, c[1].x, c[1].y);
+    const V3 v2 = mk(c[1].z, c[1].w, c[2].x), n = mk(c[2].y, c[2].z, c[2].w);
     float tt;
     bool cand;
-    const bool sphere = (rec.kind_mat & 0x80000000u) != 0u;
+    // `spheres` is wave-uniform (the scene holds any); the tag is n == 0 (rt_layout.h)
+    const bool sphere = spheres && n.x == 0.0f && n.y == 0.0f && n.z == 0.0f;
     if (!sphere) {
-        cand = tri_candidate(rec, ray, t0, tt);
+        cand = tri_candidate_leaf(v0, v1, v2, n, ray, t0, tt);
         if (COUNT)
             lc.tri++;
     } else {
-        cand = sphere_candidate(rec, ray, t0, tt);
+        cand = sphere_candidate(v0, v1.x, ray, t0, tt);
         if (COUNT)
             lc.sph++;
     }
@@ -110,48 +102,12 @@ RT_DEV void leaf_test_one(WaveLds& L, const float4 c[6], uint32_t r, uint32_t in
         atomicMin(&L.best[r], make_key(tt, index, sphere));
 }
 
-#ifdef RT_TWO_STAGE
-// Stage 2 only for lanes whose plane distance can still win: 0 <= t <= limit.
-template <bool COUNT>
-RT_DEV void leaf_test_two_stage(WaveLds& L, const float4* __restrict__ chunks, float4 c0, uint32_t r, uint32_t index,
-    LaneCounters& lc)
-{
-    const float4 a = L.rayA[r], b = L.rayB[r];
-    RayL ray;
-    ray.o = mk(a.x, a.y, a.z);
-    ray.d = mk(a.w, b.x, b.y);
-    if (COUNT) {
-        lc.tri++;
-        lc.tri_fetch++;
-    }
-    const V3 n = mk(c0.x, c0.y, c0.z);
-    const float tt = (c0.w - dot(ray.o, n)) / dot(ray.d, n);
-    const float lim = ray_limit(L, r);
-    // spheres (NaN-free D = radius, n = 0 → tt = inf or NaN) always go to stage 2
-    const bool maybe = (tt >= 0.0f && lim >= tt) || !(n.x != 0.0f || n.y != 0.0f || n.z != 0.0f);
-    if (maybe) {
-        float4 c[6];
-        c[0] = c0;
-        const float4* base = chunks + (size_t)index * 6u;
-#pragma unroll
-        for (int k = 1; k < 6; k++)
-            c[k] = base[k];
-        const PrimRecord rec = record_from_chunks(c);
-        const bool sphere = (rec.kind_mat & 0x80000000u) != 0u;
-        float t2;
-        const bool cand = sphere ? sphere_candidate(rec, ray, b.z, t2) : tri_candidate(rec, ray, b.z, t2);
-        if (cand)
-            atomicMin(&L.best[r], make_key(t2, index, sphere));
-    }
-}
-#endif
-
 // Entries [first, first + n) of the wave's leaf queue, n <= 64: two entries per
 // step, one per half-wave, one primitive per lane; the fetch of step k+1 is issued
 // before step k is tested.
 template <bool ANY, bool COUNT>
-RT_DEV void leaf_phase(WaveLds& L, const float4* __restrict__ chunks, uint32_t first, uint32_t n, uint32_t lane,
-    bool prune, LaneCounters& lc)
+RT_DEV void leaf_phase(WaveLds& L, const float4* __restrict__ leaf, bool spheres, uint32_t first, uint32_t n,
+    uint32_t lane, bool prune, LaneCounters& lc)
 {
     uint32_t my_ref = 0, my_rc = 0;
     float my_lb = 0.0f;
@@ -163,25 +119,21 @@ RT_DEV void leaf_phase(WaveLds& L, const float4* __restrict__ chunks, uint32_t f
     const bool upper = lane >= 32u;
     const uint32_t sub = lane & 31u;
     LeafSlot cur, nxt;
-    leaf_fetch<ANY>(L, chunks, my_ref, my_rc, my_lb, prune, 0u, n, upper, sub, cur);
+    leaf_fetch<ANY>(L, leaf, my_ref, my_rc, my_lb, prune, 0u, n, upper, sub, cur);
     for (uint32_t k = 0; k < n; k += 2) {
         nxt.live = false;
         nxt.cmax = 0;
         if (k + 2 < n)
-            leaf_fetch<ANY>(L, chunks, my_ref, my_rc, my_lb, prune, k + 2, n, upper, sub, nxt);
+            leaf_fetch<ANY>(L, leaf, my_ref, my_rc, my_lb, prune, k + 2, n, upper, sub, nxt);
         if (cur.live)
-#ifdef RT_TWO_STAGE
-            leaf_test_two_stage<COUNT>(L, chunks, cur.c[0], cur.r, cur.ref + sub, lc);
-#else
-            leaf_test_one<COUNT>(L, cur.c, cur.r, cur.ref + sub, lc);
-#endif
+            leaf_test_one<COUNT>(L, cur.c, cur.r, cur.ref + sub, spheres, lc);
         // leaves larger than 32 primitives (brute-force mode, very large meshes)
         for (uint32_t base = 32u; base < cur.cmax; base += 32u) {
             const uint32_t idx = base + sub;
             if (idx < cur.cnt && !(ANY && L.best[cur.r] != kNoHit)) {
-                float4 c[6];
-                load_chunks(chunks, cur.ref, cur.cnt, idx, c);
-                leaf_test_one<COUNT>(L, c, cur.r, cur.ref + idx, lc);
+                float4 c[3];
+                load_leaf(leaf, cur.ref, idx, c);
+                leaf_test_one<COUNT>(L, c, cur.r, cur.ref + idx, spheres, lc);
             }
         }
         cur = nxt;
@@ -193,7 +145,8 @@ template <bool ANY, bool COUNT>
 struct Walk {
     const SceneView& sv;
     WaveLds& L;
-    const float4* __restrict__ chunks;
+    const float4* __restrict__ leaf;
+    bool spheres; // the scene holds spheres (wave-uniform)
     LaneCounters& lc;
     uint32_t lane;
     bool prune;
@@ -210,10 +163,13 @@ struct Walk {
     RT_DEV void load_ray(uint32_t r)
     {
         if (r != cur_r) {
-            const float4 a = L.rayA[r], b = L.rayB[r];
+            const float4 a = L.rayA[r], b = L.rayB[r], c = L.rayC[r];
             cur.o = mk(a.x, a.y, a.z);
             cur.d = mk(a.w, b.x, b.y);
-            cur_inv = make_ray_inv(cur, sv.extent);
+            const uint32_t g = __float_as_uint(b.w);
+            cur_inv.y[0] = c.x, cur_inv.y[1] = c.y, cur_inv.y[2] = c.z, cur_inv.slack = c.w;
+            cur_inv.ok[0] = (g & 1u) != 0u, cur_inv.ok[1] = (g & 2u) != 0u, cur_inv.ok[2] = (g & 4u) != 0u;
+            cur_inv.all_ok = (g & 8u) != 0u;
             cur_r = r;
         }
     }
@@ -245,7 +201,7 @@ struct Walk {
             while (lq_n > 0u) {
                 const uint32_t n = lq_n < 64u ? lq_n : 64u;
                 lq_n -= n;
-                leaf_phase<ANY, COUNT>(L, chunks, lq_n, n, lane, prune, lc);
+                leaf_phase<ANY, COUNT>(L, leaf, spheres, lq_n, n, lane, prune, lc);
             }
             wave_lds_fence();
 #ifdef RT_STAMPS
@@ -259,8 +215,7 @@ struct Walk {
     RT_DEV void test_pair(const float llo[3], const float lhi[3], const float rlo[3], const float rhi[3], uint32_t r,
         bool& hl, bool& hr, float& lb_l, float& lb_r)
     {
-        hl = box_hit(llo, lhi, cur, cur_inv, lb_l);
-        hr = box_hit(rlo, rhi, cur, cur_inv, lb_r);
+        box_pair_hit(llo, lhi, rlo, rhi, cur, cur_inv, hl, hr, lb_l, lb_r);
         if (COUNT) {
             lc.box += 2;
             lc.node_fetch++;
@@ -344,12 +299,11 @@ struct Walk {
                     const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
                     const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
                     const uint4 q3 = *reinterpret_cast<const uint4*>(&np->l_ref);
-#ifdef RT_DIAG_DOUBLE_LOADS // diagnostic: 4 more L1 accesses per visit, same lines, results unused
+#if defined(RT_DIAG) && RT_DIAG == 1 // the same four loads from a second copy of the node array
                     {
-                        const volatile float4* vp = reinterpret_cast<const volatile float4*>(np);
-                        float4 d0, d1, d2, d3;
-                        d0.x = vp[0].x, d1.x = vp[1].x, d2.x = vp[2].x, d3.x = vp[3].x;
-                        asm volatile("" ::"v"(d0.x), "v"(d1.x), "v"(d2.x), "v"(d3.x));
+                        const float4* vp = reinterpret_cast<const float4*>(sv.diag_nodes + entry_node(e));
+                        const float4 d0 = vp[0], d1 = vp[1], d2 = vp[2], d3 = vp[3];
+                        asm volatile("" ::"v"(d0.x), "v"(d1.y), "v"(d2.z), "v"(d3.w));
                     }
 #endif
                     const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
@@ -361,6 +315,17 @@ struct Walk {
                     st_load += tl - tp;
 #endif
                     test_pair(llo, lhi, rlo, rhi, r, hl, hr, lb_l, lb_r);
+#if defined(RT_DIAG) && RT_DIAG == 3 // the slab arithmetic once more (children swapped), result unused
+                    {
+                        bool xl, xr;
+                        float yl, yr;
+                        const float a0[3] = { rlo[0] + 1.0f, rlo[1], rlo[2] }, a1[3] = { rhi[0] + 1.0f, rhi[1], rhi[2] };
+                        const float b0[3] = { llo[0] + 1.0f, llo[1], llo[2] }, b1[3] = { lhi[0] + 1.0f, lhi[1], lhi[2] };
+                        xl = box_hit(a0, a1, cur, cur_inv, yl);
+                        xr = box_hit(b0, b1, cur, cur_inv, yr);
+                        asm volatile("" ::"v"(yl), "v"(yr), "v"((int)xl), "v"((int)xr));
+                    }
+#endif
 #ifdef RT_STAMPS
                     asm volatile("" ::"v"(lb_l), "v"(lb_r));
                     const unsigned long long ta = clock64();
@@ -407,7 +372,7 @@ struct Walk {
 //   limit (1.0), pos >= 0 iff something blocks the ray.
 // `active` selects the lanes that carry a ray; ALL lanes of the wave must call.
 // use_bvh = features.enableAccelStructure; when false the whole array is one leaf
-// in the reference's own order (bvh.cpp:303-305; sv.chunks_flat).
+// in the reference's own order (bvh.cpp:303-305; sv.leaf_flat).
 template <bool ANY, bool COUNT>
 RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active, const RayL& ray, float& t,
     int32_t& pos, LaneCounters& lc, WaveLds& L)
@@ -419,10 +384,13 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     const uint32_t lane = lane_id();
     prune = prune && use_bvh && sv.prune_ok != 0u;
     L.rayA[lane] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
-    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t, 0.0f);
+    const RayInv inv = make_ray_inv(ray, sv.extent);
+    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t,
+        __uint_as_float((inv.ok[0] ? 1u : 0u) | (inv.ok[1] ? 2u : 0u) | (inv.ok[2] ? 4u : 0u) | (inv.all_ok ? 8u : 0u)));
+    L.rayC[lane] = make_float4(inv.y[0], inv.y[1], inv.y[2], inv.slack);
     L.best[lane] = kNoHit;
-    Walk<ANY, COUNT> w { sv, L, use_bvh ? sv.chunks : sv.chunks_flat, lc, lane, prune, 0u, ray,
-        make_ray_inv(ray, sv.extent), lane };
+    Walk<ANY, COUNT> w { sv, L, use_bvh ? sv.leaf : sv.leaf_flat, sv.prune_ok == 0u, lc, lane, prune, 0u, ray,
+        inv, lane };
 #ifdef RT_STAMPS
     const unsigned long long stamp_begin = clock64();
 #endif

@@ -30,6 +30,46 @@ __global__ __launch_bounds__(256) void k_gather(const Rec* __restrict__ tab, uin
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// Cooperative variant: 4 adjacent lanes fetch the 4 quads of one record (16 records per
+// load instruction, 4 instructions for the wave's 64 records), transposed back through LDS.
+__global__ __launch_bounds__(256) void k_gather_quad(const Rec* __restrict__ tab, uint32_t mask, int iters, float* out)
+{
+    __shared__ float4 stage[4][64 * 4 + 4];
+    float4* st = stage[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    float acc = 0.f;
+    for (int i = 0; i < iters; i++) {
+        float4 v[4];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t src = 16u * k + (lane >> 2);
+            const uint32_t r = __shfl(idx, src, 64) & mask;
+            v[k] = tab[r].q[lane & 3u];
+        }
+        for (int k = 0; k < 4; k++)
+            st[(16u * k + (lane >> 2)) * 4u + (lane & 3u)] = v[k];
+        __builtin_amdgcn_wave_barrier();
+        const float4 a0 = st[lane * 4u], a1 = st[lane * 4u + 1], a2 = st[lane * 4u + 2], a3 = st[lane * 4u + 3];
+        __builtin_amdgcn_wave_barrier();
+        acc += a0.x + a1.y + a2.z;
+        idx = idx * 1664525u + 1013904223u + __float_as_uint(a3.w);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+// Narrow variant: one dword per lane per record (is the cost per access or per byte?)
+__global__ __launch_bounds__(256) void k_gather_dword(const Rec* __restrict__ tab, uint32_t mask, int iters, float* out)
+{
+    uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    float acc = 0.f;
+    for (int i = 0; i < iters; i++) {
+        const float w = tab[idx & mask].q[3].w;
+        acc += w;
+        idx = idx * 1664525u + 1013904223u + __float_as_uint(w);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -49,13 +89,17 @@ int main()
         Rec* tab;
         hipMalloc(&tab, (size_t)n * 64);
         hipMemcpy(tab, h.data(), (size_t)n * 64, hipMemcpyHostToDevice);
-        for (int blocks_per_cu : { 1, 2, 3, 4, 8 }) {
-            for (int ilp : { 1, 2 }) {
+        for (int blocks_per_cu : { 2, 4 }) {
+            for (int ilp : { 1, 2, 3, 4 }) {
                 const int iters = 400;
                 const int grid = cus * blocks_per_cu;
                 for (int rep = 0; rep < 2; rep++) {
                     hipEventRecord(e0);
-                    if (ilp == 1)
+                    if (ilp == 3)
+                        hipLaunchKernelGGL(k_gather_quad, dim3(grid), dim3(256), 0, 0, tab, n - 1, iters, out);
+                    else if (ilp == 4)
+                        hipLaunchKernelGGL(k_gather_dword, dim3(grid), dim3(256), 0, 0, tab, n - 1, iters, out);
+                    else if (ilp == 1)
                         hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(256), 0, 0, tab, n - 1, iters, out);
                     else
                         hipLaunchKernelGGL(k_gather<2>, dim3(grid), dim3(256), 0, 0, tab, n - 1, iters, out);
@@ -64,9 +108,9 @@ int main()
                 }
                 float ms;
                 hipEventElapsedTime(&ms, e0, e1);
-                const double recs = (double)grid * 256 * iters * ilp;
+                const double recs = (double)grid * 256 * iters * (ilp == 2 ? 2 : 1);
                 const double cyc = ms * 1e-3 * 2.4e9;
-                printf("table %3zu MB  waves/CU %2d  ilp %d : %.3f ms  %.4f records/cycle/CU  (%.1f cycles per 64-lane gather step)  %.2f TB/s useful\n",
+                printf("table %3zu MB  waves/CU %2d  mode %d (1,2 = per-lane ILP; 3 = quad-cooperative; 4 = one dword) : %.3f ms  %.4f records/cycle/CU  (%.1f cycles per 64-lane gather step)  %.2f TB/s useful\n",
                     mb, blocks_per_cu * 4, ilp, ms, recs / cyc / cus, 64.0 / (recs / cyc / cus) , recs * 64 / (ms * 1e-3) / 1e12);
             }
         }
