@@ -341,6 +341,11 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
         child_ref(nodes[i].right, p.r_ref, p.r_cnt);
     }
     child_ref(root, root_ref, root_cnt);
+    bounds_finite = true;
+    for (const NodePair& p : pairs)
+        for (int a = 0; a < 3; a++)
+            bounds_finite = bounds_finite && std::isfinite(p.l_lo[a]) && std::isfinite(p.l_hi[a])
+                && std::isfinite(p.r_lo[a]) && std::isfinite(p.r_hi[a]);
     if (pairs.empty())
         pairs.emplace_back(); // keep the device array non-empty
     // MAX_DEPTH = 16 caps a tree at 2^15 - 1 internal nodes; the traversal's packed deque

@@ -50,6 +50,7 @@ struct HostBvh {
     std::vector<RefNode> nodes;      // post-order, root = last
     std::vector<int32_t> prim_order; // permuted position → prim id
     std::vector<NodePair> pairs;     // one per internal node
+    bool bounds_finite = true;       // every bound of every pair is a finite float
     std::vector<PrimRecord> records;      // the reference's visit order (leaves right-first) — BVH mode
     std::vector<PrimRecord> records_flat; // the reference's array order — brute-force mode
     uint32_t root_ref = 0, root_cnt = 0;

@@ -161,6 +161,8 @@ struct rt_bvh {
         v.root_ref = host.root_ref;
         v.root_cnt = host.root_cnt;
         v.n_prims = (uint32_t)host.records.size();
+        v.n_pairs = (uint32_t)host.pairs.size();
+        v.bounds_finite = host.bounds_finite ? 1u : 0u;
         v.prune_ok = scene->host.spheres.empty() ? 1u : 0u;
         v.extent = scene->host.extent;
         v.leaf_flush = (uint32_t)g_leaf_flush.load();

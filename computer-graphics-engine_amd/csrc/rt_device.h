@@ -100,6 +100,21 @@ RT_DEV void wave_lds_fence()
 #define RT_STAMP_ADD(slot, a, b)
 #endif
 
+// 128-bit buffer loads through a resource descriptor: a 32-bit byte offset per lane instead
+// of 64-bit address arithmetic, hardware range check, and exactly one dwordx4 per call
+// (the compiler splits and overlaps plain float4 loads whose components it tracks one by one).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+RT_DEV BufRsrc make_rsrc(const void* p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+RT_DEV float4 buf_load16(BufRsrc r, uint32_t byte_off)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 struct LaneCounters {
     uint32_t box = 0, tri = 0, sph = 0;     // lane-level tests
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
@@ -153,14 +168,17 @@ RT_DEV uint32_t entry_ray(uint32_t e) { return e & 63u; }
 // for everything else.
 struct RayInv {
     float y[3]; // RN(1 / d[a])
-    bool ok[3];
-    bool all_ok; // ok on all three axes (then no component of d is zero either)
+    uint32_t guard; // bit a: axis a may use the reciprocal; bit 3: all three may AND the origin is
+                    // finite (then no component of d is zero, and no slab quotient can be NaN)
+    RT_DEV bool ok(int a) const { return (guard >> a) & 1u; }
+    RT_DEV bool all_ok() const { return (guard & 8u) != 0u; }
     float slack; // rho * max_a |1/d[a]|: how far a slab plane moved by rho shifts t (pruning bound)
 };
 // `extent` = largest |coordinate| of the scene (SceneView::extent).
 RT_DEV RayInv make_ray_inv(const RayL& r, float extent)
 {
     RayInv v;
+    v.guard = 0u;
     const float d[3] = { r.d.x, r.d.y, r.d.z };
     float ymax = 0.0f;
 #pragma unroll
@@ -168,14 +186,18 @@ RT_DEV RayInv make_ray_inv(const RayL& r, float extent)
         v.y[a] = 1.0f / d[a];
         const uint32_t b = __float_as_uint(d[a]);
         const uint32_t e = (b >> 23) & 0xffu;
-        v.ok[a] = e >= 127u - 40u && e <= 127u + 40u && (b & 0x7fffffu) != 0x7fffffu;
+        if (e >= 127u - 40u && e <= 127u + 40u && (b & 0x7fffffu) != 0x7fffffu)
+            v.guard |= 1u << a;
         if (d[a] != 0.0f)
             ymax = fmaxf(ymax, fabsf(v.y[a]));
     }
     // rho (see "Pruning" below): 2^-16 of the largest coordinate magnitude in play
     const float S = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fmaxf(fabsf(r.o.z), extent));
     v.slack = (S * 1.52587890625e-05f) * ymax;
-    v.all_ok = v.ok[0] && v.ok[1] && v.ok[2];
+    const float omax = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
+    const bool o_finite = r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z && omax < __builtin_inff();
+    if (v.guard == 7u && o_finite)
+        v.guard = 15u;
     return v;
 }
 RT_DEV float div_by_ray(float n, float d, float y, bool ok)
@@ -219,8 +241,8 @@ RT_DEV void slab_quotients(const float lo[3], const float hi[3], const RayL& r, 
             tl[a] = kFltMin;
             th[a] = kFltMax;
         } else {
-            tl[a] = div_by_ray(lo[a] - o[a], d[a], inv.y[a], inv.ok[a]);
-            th[a] = div_by_ray(hi[a] - o[a], d[a], inv.y[a], inv.ok[a]);
+            tl[a] = div_by_ray(lo[a] - o[a], d[a], inv.y[a], inv.ok(a));
+            th[a] = div_by_ray(hi[a] - o[a], d[a], inv.y[a], inv.ok(a));
         }
     }
 }
@@ -252,11 +274,12 @@ RT_DEV bool box_hit(const float lo[3], const float hi[3], const RayL& r, const R
 // Both boxes of a node pair. The twelve quotients share ONE guard: when the ray's three
 // reciprocals are usable (all_ok) and every numerator's magnitude lies in
 // [2^-60, 2^61) — the same windows div_by_ray checks one by one — all twelve take the
-// three-instruction path without a branch each; otherwise (origin exactly on a slab
+// three-instruction path without a branch each (`bounds_finite`: no node bound of the
+// tree is NaN or infinite — SceneView::bounds_finite); otherwise (origin exactly on a slab
 // plane, an axis-parallel ray, extreme values) the pair falls back to the guarded
 // per-quotient code. Same results either way, ~half the instructions on the hot path.
 RT_DEV void box_pair_hit(const float llo[3], const float lhi[3], const float rlo[3], const float rhi[3],
-    const RayL& r, const RayInv& inv, bool& hl, bool& hr, float& lb_l, float& lb_r)
+    const RayL& r, const RayInv& inv, bool bounds_finite, bool& hl, bool& hr, float& lb_l, float& lb_r)
 {
     const float o[3] = { r.o.x, r.o.y, r.o.z };
     const float d[3] = { r.d.x, r.d.y, r.d.z };
@@ -274,23 +297,36 @@ RT_DEV void box_pair_hit(const float llo[3], const float lhi[3], const float rlo
         amin = fminf(amin, fabsf(n[i])); // fminf / fmaxf skip a NaN numerator: it needs no guard,
         amax = fmaxf(amax, fabsf(n[i])); // both paths turn it into a NaN quotient
     }
-    float tl_l[3], th_l[3], tl_r[3], th_r[3];
-    if (inv.all_ok && amin >= 0x1p-60f && amax < 0x1p61f) {
+    if (inv.all_ok() && bounds_finite && amin >= 0x1p-60f && amax < 0x1p61f) {
+        // Every quotient is finite here, so IEEE min / max (v_min_f32, v_max3_f32: one
+        // instruction each) agree with the reference's compare-and-select up to the sign
+        // of a zero, which no comparison below can see; slab_decide() reduces to
+        //   tin < 0 ? tout > 0 : tin <= tout.
+        float q[12];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const float y = inv.y[a], nd = -d[a];
-            float q;
-            q = n[a] * y, tl_l[a] = __builtin_fmaf(__builtin_fmaf(nd, q, n[a]), y, q);
-            q = n[3 + a] * y, th_l[a] = __builtin_fmaf(__builtin_fmaf(nd, q, n[3 + a]), y, q);
-            q = n[6 + a] * y, tl_r[a] = __builtin_fmaf(__builtin_fmaf(nd, q, n[6 + a]), y, q);
-            q = n[9 + a] * y, th_r[a] = __builtin_fmaf(__builtin_fmaf(nd, q, n[9 + a]), y, q);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float q0 = n[3 * k + a] * y;
+                q[3 * k + a] = __builtin_fmaf(__builtin_fmaf(nd, q0, n[3 * k + a]), y, q0);
+            }
         }
+        const float tin_l = fmaxf(fmaxf(fminf(q[0], q[3]), fminf(q[1], q[4])), fminf(q[2], q[5]));
+        const float tout_l = fminf(fminf(fmaxf(q[0], q[3]), fmaxf(q[1], q[4])), fmaxf(q[2], q[5]));
+        const float tin_r = fmaxf(fmaxf(fminf(q[6], q[9]), fminf(q[7], q[10])), fminf(q[8], q[11]));
+        const float tout_r = fminf(fminf(fmaxf(q[6], q[9]), fmaxf(q[7], q[10])), fmaxf(q[8], q[11]));
+        lb_l = tin_l * 0.99999904632568359375f - inv.slack;
+        lb_r = tin_r * 0.99999904632568359375f - inv.slack;
+        hl = tin_l < 0.0f ? tout_l > 0.0f : tin_l <= tout_l;
+        hr = tin_r < 0.0f ? tout_r > 0.0f : tin_r <= tout_r;
     } else {
+        float tl_l[3], th_l[3], tl_r[3], th_r[3];
         slab_quotients(llo, lhi, r, inv, tl_l, th_l);
         slab_quotients(rlo, rhi, r, inv, tl_r, th_r);
+        hl = slab_decide(tl_l, th_l, inv.slack, lb_l);
+        hr = slab_decide(tl_r, th_r, inv.slack, lb_r);
     }
-    hl = slab_decide(tl_l, th_l, inv.slack, lb_l);
-    hr = slab_decide(tl_r, th_r, inv.slack, lb_r);
 }
 
 // A.2: t of the ray with the triangle's plane (n, D precomputed on the host with

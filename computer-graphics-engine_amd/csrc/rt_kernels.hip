@@ -471,10 +471,10 @@ __global__ __launch_bounds__(256) void k_div_check(uint32_t seed, uint32_t mode,
         RayL r;
         r.o = mk(0, 0, 0), r.d = mk(d, d, d);
         const RayInv inv = make_ray_inv(r, 1.0f);
-        const float q = div_by_ray(n, d, inv.y[0], inv.ok[0]);
+        const float q = div_by_ray(n, d, inv.y[0], inv.ok(0));
         const float ref = n / d;
         const uint32_t ne = (__float_as_uint(n) >> 23) & 0xffu;
-        if (inv.ok[0] && ne >= 127u - 60u && ne <= 127u + 60u)
+        if (inv.ok(0) && ne >= 127u - 60u && ne <= 127u + 60u)
             fast++;
         const bool same = __float_as_uint(q) == __float_as_uint(ref) || (q != q && ref != ref);
         if (!same) {

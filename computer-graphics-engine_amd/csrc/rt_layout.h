@@ -106,6 +106,8 @@ struct SceneView {
     uint32_t n_lights;
     uint32_t root_ref, root_cnt; // child reference of the root (never box-tested: bvh.cpp:313)
     uint32_t n_prims;
+    uint32_t n_pairs; // internal nodes (NodePair records)
+    uint32_t bounds_finite; // no node bound is NaN / infinite (rt_device.h: box_pair_hit fast path)
     uint32_t prune_ok; // 0 when the scene holds spheres (rt_device.h: Pruning)
     float extent;      // largest |coordinate| of any vertex
     unsigned long long* stamps; // diagnostic builds (-DRT_STAMPS) only, else NULL

@@ -32,16 +32,16 @@ struct LeafSlot {
 };
 
 // the three 16-byte words of primitive (ref + i)
-RT_DEV void load_leaf(const float4* __restrict__ leaf, uint32_t ref, uint32_t i, float4 c[3])
+RT_DEV void load_leaf(BufRsrc leaf, uint32_t ref, uint32_t i, float4 c[3])
 {
-    const float4* base = leaf + ((size_t)ref + i) * 3u;
+    const uint32_t off = (ref + i) * 48u;
 #pragma unroll
     for (int k = 0; k < 3; k++)
-        c[k] = base[k];
+        c[k] = buf_load16(leaf, off + 16u * k);
 }
 
 template <bool ANY>
-RT_DEV void leaf_fetch(const WaveLds& L, const float4* __restrict__ leaf, uint32_t my_ref, uint32_t my_rc,
+RT_DEV void leaf_fetch(const WaveLds& L, BufRsrc leaf, uint32_t my_ref, uint32_t my_rc,
     float my_lb, bool prune, uint32_t k, uint32_t n, bool upper, uint32_t sub, LeafSlot& s)
 {
     const uint32_t ref0 = read_lane(my_ref, k), rc0 = read_lane(my_rc, k);
@@ -66,7 +66,7 @@ RT_DEV void leaf_fetch(const WaveLds& L, const float4* __restrict__ leaf, uint32
 #if defined(RT_DIAG) && RT_DIAG == 2 // the same three loads from a second copy of the leaf array
     if (s.live) {
         float4 d[3];
-        load_leaf(g_diag_leaf, s.ref, sub, d);
+        load_leaf(make_rsrc(g_diag_leaf, 0x7fffffffu), s.ref, sub, d);
         asm volatile("" ::"v"(d[0].x), "v"(d[1].y), "v"(d[2].z));
     }
 #endif
@@ -106,7 +106,7 @@ RT_DEV void leaf_test_one(WaveLds& L, const float4 c[3], uint32_t r, uint32_t in
 // step, one per half-wave, one primitive per lane; the fetch of step k+1 is issued
 // before step k is tested.
 template <bool ANY, bool COUNT>
-RT_DEV void leaf_phase(WaveLds& L, const float4* __restrict__ leaf, bool spheres, uint32_t first, uint32_t n,
+RT_DEV void leaf_phase(WaveLds& L, BufRsrc leaf, bool spheres, uint32_t first, uint32_t n,
     uint32_t lane, bool prune, LaneCounters& lc)
 {
     uint32_t my_ref = 0, my_rc = 0;
@@ -145,7 +145,7 @@ template <bool ANY, bool COUNT>
 struct Walk {
     const SceneView& sv;
     WaveLds& L;
-    const float4* __restrict__ leaf;
+    BufRsrc leaf, nodes; // LeafRecord / NodePair arrays
     bool spheres; // the scene holds spheres (wave-uniform)
     LaneCounters& lc;
     uint32_t lane;
@@ -166,10 +166,8 @@ struct Walk {
             const float4 a = L.rayA[r], b = L.rayB[r], c = L.rayC[r];
             cur.o = mk(a.x, a.y, a.z);
             cur.d = mk(a.w, b.x, b.y);
-            const uint32_t g = __float_as_uint(b.w);
             cur_inv.y[0] = c.x, cur_inv.y[1] = c.y, cur_inv.y[2] = c.z, cur_inv.slack = c.w;
-            cur_inv.ok[0] = (g & 1u) != 0u, cur_inv.ok[1] = (g & 2u) != 0u, cur_inv.ok[2] = (g & 4u) != 0u;
-            cur_inv.all_ok = (g & 8u) != 0u;
+            cur_inv.guard = __float_as_uint(b.w);
             cur_r = r;
         }
     }
@@ -215,7 +213,7 @@ struct Walk {
     RT_DEV void test_pair(const float llo[3], const float lhi[3], const float rlo[3], const float rhi[3], uint32_t r,
         bool& hl, bool& hr, float& lb_l, float& lb_r)
     {
-        box_pair_hit(llo, lhi, rlo, rhi, cur, cur_inv, hl, hr, lb_l, lb_r);
+        box_pair_hit(llo, lhi, rlo, rhi, cur, cur_inv, sv.bounds_finite != 0u, hl, hr, lb_l, lb_r);
         if (COUNT) {
             lc.box += 2;
             lc.node_fetch++;
@@ -294,11 +292,13 @@ struct Walk {
                     const unsigned long long tp = clock64();
                     st_pop += tp - ts1;
 #endif
-                    const NodePair* np = sv.nodes + entry_node(e);
-                    const float4 q0 = *reinterpret_cast<const float4*>(&np->l_lo[0]); // l_lo xyz, l_hi x
-                    const float4 q1 = *reinterpret_cast<const float4*>(&np->l_hi[1]); // l_hi yz, r_lo xy
-                    const float4 q2 = *reinterpret_cast<const float4*>(&np->r_lo[2]); // r_lo z, r_hi xyz
-                    const uint4 q3 = *reinterpret_cast<const uint4*>(&np->l_ref);
+                    const uint32_t noff = entry_node(e) * 64u;
+                    const float4 q0 = buf_load16(nodes, noff);       // l_lo xyz, l_hi x
+                    const float4 q1 = buf_load16(nodes, noff + 16u); // l_hi yz, r_lo xy
+                    const float4 q2 = buf_load16(nodes, noff + 32u); // r_lo z, r_hi xyz
+                    const float4 q3f = buf_load16(nodes, noff + 48u);
+                    const uint4 q3 = make_uint4(__float_as_uint(q3f.x), __float_as_uint(q3f.y), __float_as_uint(q3f.z),
+                        __float_as_uint(q3f.w));
 #if defined(RT_DIAG) && RT_DIAG == 1 // the same four loads from a second copy of the node array
                     {
                         const float4* vp = reinterpret_cast<const float4*>(sv.diag_nodes + entry_node(e));
@@ -334,17 +334,14 @@ struct Walk {
                     l_ref = q3.x, l_cnt = q3.y, r_ref = q3.z, r_cnt = q3.w;
                     const bool push_l = hl && l_cnt == 0u, push_r = hr && r_cnt == 0u;
                     // the nearer child goes on top (popped first): finds close hits early
-                    const bool l_first = push_l && (!push_r || lb_l > lb_r);
-                    if (push_l && l_first) {
-                        L.stack[row0 + sp][lane] = pack_entry(l_ref, r, lb_l);
+                    const uint32_t e_l = pack_entry(l_ref, r, lb_l), e_r = pack_entry(r_ref, r, lb_r);
+                    const bool both = push_l && push_r, l_far = lb_l > lb_r;
+                    if (push_l || push_r) {
+                        L.stack[row0 + sp][lane] = both ? (l_far ? e_l : e_r) : (push_l ? e_l : e_r);
                         sp++;
                     }
-                    if (push_r) {
-                        L.stack[row0 + sp][lane] = pack_entry(r_ref, r, lb_r);
-                        sp++;
-                    }
-                    if (push_l && !l_first) {
-                        L.stack[row0 + sp][lane] = pack_entry(l_ref, r, lb_l);
+                    if (both) {
+                        L.stack[row0 + sp][lane] = l_far ? e_r : e_l;
                         sp++;
                     }
                     leaf_l = hl && l_cnt != 0u;
@@ -385,12 +382,11 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     prune = prune && use_bvh && sv.prune_ok != 0u;
     L.rayA[lane] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
     const RayInv inv = make_ray_inv(ray, sv.extent);
-    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t,
-        __uint_as_float((inv.ok[0] ? 1u : 0u) | (inv.ok[1] ? 2u : 0u) | (inv.ok[2] ? 4u : 0u) | (inv.all_ok ? 8u : 0u)));
+    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t, __uint_as_float(inv.guard));
     L.rayC[lane] = make_float4(inv.y[0], inv.y[1], inv.y[2], inv.slack);
     L.best[lane] = kNoHit;
-    Walk<ANY, COUNT> w { sv, L, use_bvh ? sv.leaf : sv.leaf_flat, sv.prune_ok == 0u, lc, lane, prune, 0u, ray,
-        inv, lane };
+    Walk<ANY, COUNT> w { sv, L, make_rsrc(use_bvh ? sv.leaf : sv.leaf_flat, sv.n_prims * 48u),
+        make_rsrc(sv.nodes, sv.n_pairs * 64u), sv.prune_ok == 0u, lc, lane, prune, 0u, ray, inv, lane };
 #ifdef RT_STAMPS
     const unsigned long long stamp_begin = clock64();
 #endif
