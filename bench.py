@@ -156,7 +156,10 @@ def main():
         if use_events and launches:
             # this rank's share of the algorithmic bytes / its own kernel time
             ab_rank = algorithmic_bytes(cnt, f, 0)["trace_kernel"]
-            per_launch_bytes = ab_rank / n_levels
+            # launches per frame: 1 with the default fused recursion (the wave keeps its own
+            # reflection rays), depth + 1 with rt_set_option("fused", 0)
+            per_frame = launches / args.steps
+            per_launch_bytes = ab_rank / per_frame
             avg_launch_s = kernel_ms / 1e3 / launches
             achieved = per_launch_bytes / avg_launch_s / 1e9
             traffic = None
@@ -169,7 +172,7 @@ def main():
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
                         "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": launches,
-                        "launches_per_frame": n_levels}
+                        "launches_per_frame": round(per_frame, 3)}
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, data, scenes)

@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 3 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 };
+std::atomic<int> g_tile_wlog { 2 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -284,11 +284,13 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.depth = n_levels - 1;
     a.parallelogram_n = p.parallelogram_n, a.segment_n = p.segment_n, a.seed = p.seed;
     a.min_waves = (uint32_t)g_min_waves.load();
+    a.fused = g_fused.load() ? 1u : 0u;
+    a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
     a.state = sc.state.p;
     a.n_items = n_items;
     a.counters = counters_dev;
-    for (int32_t level = 0; level < n_levels; level++) {
+    for (int32_t level = 0; level < (a.fused ? 1 : n_levels); level++) {
         a.level = level;
         a.direct = sc.direct.p + (size_t)level * n_items * 3;
         if (level == 0) {
@@ -389,6 +391,10 @@ int rt_set_option(const char* name, int value)
         if (value < 0 || value > 3)
             return fail(RT_ERR_INVALID, "rt_set_option: tile_wlog / tile_hlog must be in [0, 3]");
         (name[5] == 'w' ? g_tile_wlog : g_tile_hlog).store(value);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "fused") == 0) { // 1: all recursion levels in one launch (default); 0: one launch per level
+        g_fused.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "super_log") == 0) {

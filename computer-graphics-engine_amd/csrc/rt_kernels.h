@@ -42,6 +42,8 @@ struct LevelArgs {
     const uint32_t* in_count; // device count for SRC_QUEUE
     uint32_t in_count_imm;    // count for SRC_RAYS
     uint32_t min_waves;       // sparse levels: fewer rays per wave until this many waves are busy
+    uint32_t fused;           // 1: the wave traces its own reflection rays, all levels in this launch
+    size_t level_stride;      // floats between the `direct` planes of consecutive levels
     RaySoA out;
     uint32_t* out_count;
     float* direct;   // this level's direct-light colours, n_items * 3

@@ -189,14 +189,16 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     __shared__ WaveLds lds[kBlock / 64];
     WaveLds& wl = lds[threadIdx.x >> 6];
 
+    const int32_t first_level = a.level;
+    for (int32_t level = first_level;; level++) {
     // ---- closest hit (bvh.intersect, render.cpp:31) -----------------------------
     int32_t pos;
     traverse<false, COUNT>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
     const bool hit = active && pos >= 0;
     if (active) {
         if (hit)
-            a.state[item] = (uint32_t)a.level + 1u;
-        else if (a.level == 0)
+            a.state[item] = (uint32_t)level + 1u;
+        else if (level == 0)
             a.state[item] = 0u;
         else
             a.state[item] |= 0x100u; // the reflected ray left the scene: Lo += vec3(0) twice
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
                 } else if (kind == RT_LIGHT_SEGMENT) { // sampleSegmentLight, light.cpp:19-26
                     const V3 e0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]), e1 = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
                     const V3 c0 = mk(L->v[2][0], L->v[2][1], L->v[2][2]), c1 = mk(L->v[3][0], L->v[3][1], L->v[3][2]);
-                    const float r = rand01(rand31(a.seed, pixel, (uint32_t)a.level, li, (uint32_t)s, 0u));
+                    const float r = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
                     const float weight = ((float)s + r) / (float)a.segment_n;
                     lpos = (e1 - e0) * weight + e0;
                     lcol = weight * c1 + (1 - weight) * c0;
@@ -243,8 +245,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
                     const V3 e01 = mk(L->v[1][0], L->v[1][1], L->v[1][2]), e02 = mk(L->v[2][0], L->v[2][1], L->v[2][2]);
                     const V3 c0 = mk(L->v[3][0], L->v[3][1], L->v[3][2]), c1 = mk(L->v[4][0], L->v[4][1], L->v[4][2]);
                     const V3 c2 = mk(L->v[5][0], L->v[5][1], L->v[5][2]), c3 = mk(L->v[6][0], L->v[6][1], L->v[6][2]);
-                    const float horRandom = rand01(rand31(a.seed, pixel, (uint32_t)a.level, li, (uint32_t)s, 0u));
-                    const float verRandom = rand01(rand31(a.seed, pixel, (uint32_t)a.level, li, (uint32_t)s, 1u));
+                    const float horRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
+                    const float verRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 1u));
                     const float horWeight = ((float)i + horRandom) / (float)n;
                     const float verWeight = ((float)k + verRandom) / (float)n;
                     const V3 horVector = horWeight * e01;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         Lo = result;
     }
     if (hit) {
-        float* d = a.direct + 3 * (size_t)item;
+        float* d = a.direct + (size_t)(level - first_level) * a.level_stride + 3 * (size_t)item;
         d[0] = Lo.x, d[1] = Lo.y, d[2] = Lo.z;
     }
 
@@ -289,11 +291,29 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     bool spawn = false;
     RayL refl;
     refl.o = mk(0, 0, 0), refl.d = mk(0, 0, 0);
-    if (hit && (flags & F_RECURSIVE) && a.level < a.depth)
+    if (hit && (flags & F_RECURSIVE) && level < a.depth)
         spawn = compute_reflection_ray(ray, t, h, refl);
     const uint64_t smask = ballot(spawn);
     if (COUNT && spawn)
         rc.queued = 1;
+    if (COUNT) {
+        flush_counters(a.counters, lc, rc, level, lane);
+        lc = LaneCounters();
+        rc = RayCounts();
+    }
+    if (a.fused) {
+        // The wave keeps its own reflection rays and traces them at once: lanes whose
+        // path ended idle and pick up subtrees of the others by work stealing. No global
+        // queue, no launch per level, and deep sparse levels overlap with everything else.
+        if (smask == 0)
+            break;
+        active = spawn;
+        ray = refl;
+        t = kFltMax;
+        if (COUNT && active)
+            rc.closest = 1;
+        continue;
+    }
     if (smask) {
         uint32_t base = 0;
         if (lane == 0)
@@ -311,8 +331,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
             }
         }
     }
-    if (COUNT)
-        flush_counters(a.counters, lc, rc, a.level, lane);
+    break;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fold(const FoldArgs a)

@@ -16,7 +16,9 @@ shutil.copy(ks, dst / f"{tag}_rocprofv3_kernel_stats.csv")
 rows = list(csv.DictReader(open(glob.glob(str(src / "stats" / "*" / "*_kernel_trace.csv"))[0])))
 tr = [r for r in rows if "k_trace_level<false>" in r["Kernel_Name"]]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
-levels = [dur[i::5][-20:] for i in range(5)] if len(dur) % 5 == 0 else []
+bench = json.loads(open(src / "bench_default.json").read().strip().splitlines()[-1])
+LPF = max(1, int(round(bench["roofline"]["launches_per_frame"])))  # k_trace_level launches per frame (1 = fused)
+levels = [dur[i::LPF][-20:] for i in range(LPF)] if len(dur) % LPF == 0 else []
 pm = {}
 for f in sorted(glob.glob(str(src / "pmc" / "*" / "*" / "*_counter_collection.csv"))):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -25,20 +27,19 @@ for f in sorted(glob.glob(str(src / "pmc" / "*" / "*" / "*_counter_collection.cs
             per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     for c, d in per.items():
         ids = sorted(d)
-        pm[c] = [d[i] for i in ids][-5:]          # the last frame's five level launches
-bench = json.loads(open(src / "bench_default.json").read().strip().splitlines()[-1])
+        pm[c] = [d[i] for i in ids][-LPF:]        # the last frame's level launches
 summary = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline")},
            "trace_level_launch_us_by_level": [round(sum(l) / len(l), 1) for l in levels] if levels else None,
            "pmc_last_frame_by_level": pm}
 json.dump(summary, open(dst / f"{tag}_profile_summary.json", "w"), indent=1)
 if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
     # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports 1/2 of
-    # the bytes of 16 B/lane reads → doubled; WRITE_SIZE exact. Per launch = frame total / 5.
+    # the bytes of 16 B/lane reads → doubled; WRITE_SIZE exact. Per launch = frame total / launches per frame.
     fetch, write = sum(pm["FETCH_SIZE"]), sum(pm["WRITE_SIZE"])
-    per_launch = (2.0 * fetch + write) * 1024.0 / 5.0
+    per_launch = (2.0 * fetch + write) * 1024.0 / LPF
     json.dump({"workload": "C3", "hbm_bytes_per_launch": int(per_launch),
                "fetch_size_kb_frame": fetch, "write_size_kb_frame": write,
-               "correction": "2 x FETCH_SIZE (gfx950, 16 B/lane loads; gather pattern uncalibrated) + WRITE_SIZE, x1024, / 5 launches",
+               "correction": "2 x FETCH_SIZE (gfx950, 16 B/lane loads; gather pattern uncalibrated) + WRITE_SIZE, x1024, / launches per frame",
                "source": f"profiles/{tag}_profile_summary.json"}, open(dst / "hbm_traffic.json", "w"), indent=1)
 print(json.dumps(summary["bench"]["roofline"]), summary["trace_level_launch_us_by_level"])
 print(open(dst / f"{tag}_rocprofv3_kernel_stats.csv").read()[:900])

@@ -37,7 +37,10 @@ stream = torch.cuda.current_stream().cuda_stream
 R = sharding.StripRenderer(rt, bvh, cam, f, p, cfg.width, cfg.height)
 res = {v: [] for v in values}
 cnts = {}
-for rnd in range(4):
+import os
+ROUNDS = int(os.environ.get('TUNE_ROUNDS', '4'))
+FRAMES = int(os.environ.get('TUNE_FRAMES', '20'))
+for rnd in range(ROUNDS):
     for v in values:
         apply(v)
         if rnd == 0:
@@ -47,10 +50,10 @@ for rnd in range(4):
             R.step(stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(FRAMES):
             R.step(stream)
         torch.cuda.synchronize()
-        res[v].append((time.perf_counter() - t0) / 20 * 1e3)
+        res[v].append((time.perf_counter() - t0) / FRAMES * 1e3)
 for v in values:
     c = cnts[v]
-    print(f"{name}={v!s:>28}  ms/frame median {np.median(res[v]):.3f} min {min(res[v]):.3f}  box {c['box_tests']/1e6:.1f}M tri {c['tri_tests']/1e6:.1f}M rays {c['rays']}")
+    print(f"{name}={v!s:>28}  ms/frame median {np.median(res[v]):.3f} min {min(res[v]):.3f}  box {c['box_tests']/1e6:.1f}M tri {c['tri_tests']/1e6:.1f}M rays {c['rays']}  rounds " + " ".join(f"{x:.3f}" for x in res[v]))
