@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 2 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 };
+std::atomic<int> g_tile_wlog { 2 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 0 }, g_share { 0 }, g_prio { 0 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -88,6 +88,12 @@ struct Scratch {
     DevBuf<uint32_t> counts;
     DevBuf<int32_t> rows;
     std::vector<int32_t> rows_host;
+    DevBuf<uint32_t> order; // tile dispatch order (tile_order_for)
+    // tail work sharing of fused launches (rt_kernels.h ShareArgs)
+    DevBuf<uint32_t> share_sched;
+    DevBuf<unsigned long long> share_queue;
+    DevBuf<float4> share_rays;
+    std::vector<int64_t> order_key;
     DevBuf<float> frame;      // device frame for host-output calls
     DevBuf<float> in_ray, in_t; // uploaded user rays
     DevBuf<uint32_t> in_pixel;
@@ -253,7 +259,47 @@ rt::CameraArgs camera_args(const rt_camera& c, int32_t w, int32_t h)
     a.rows = nullptr, a.row0 = 0, a.n_rows = h;
     a.tile_wlog = (uint32_t)g_tile_wlog.load(), a.tile_hlog = (uint32_t)g_tile_hlog.load();
     a.super_log = (uint32_t)g_super_log.load();
+    a.order = nullptr;
     return a;
+}
+
+// Dispatch order of the primary tiles: nearest to the image centre first. Workgroups start
+// in index order, and with the recursion fused into one launch a tile's whole path tree is
+// one wave's serial work; tiles that see geometry (usually around the centre) must start
+// early or their chains form a tail with most of the chip idle (tools/timeline.py: half of
+// the launch on the bench scene). Purely a scheduling choice — results do not depend on it.
+int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
+{
+    if (!g_tile_order.load() || cam.super_log != 0)
+        return RT_OK;
+    const int64_t tw = 1 << cam.tile_wlog, th = 1 << cam.tile_hlog;
+    const int64_t tiles_x = (cam.width + tw - 1) / tw, tiles_y = (cam.n_rows + th - 1) / th;
+    std::vector<int64_t> key { cam.width, cam.height, cam.n_rows, cam.row0, tw, th, cam.rows ? 1 : 0 };
+    if (cam.rows)
+        key.insert(key.end(), sc.rows_host.begin(), sc.rows_host.end());
+    if (key != sc.order_key || !sc.order.p) {
+        const size_t n = (size_t)(tiles_x * tiles_y);
+        std::vector<std::pair<int64_t, uint32_t>> d(n);
+        for (int64_t ty = 0; ty < tiles_y; ty++) {
+            const int64_t lrow = std::min<int64_t>(ty * th + th / 2, cam.n_rows - 1);
+            const int64_t y = cam.rows ? sc.rows_host[(size_t)lrow] : cam.row0 + lrow;
+            for (int64_t tx = 0; tx < tiles_x; tx++) {
+                const int64_t x = tx * tw + tw / 2;
+                const int64_t dx = 2 * x - cam.width, dy = 2 * y - cam.height;
+                d[(size_t)(ty * tiles_x + tx)] = { dx * dx + dy * dy, (uint32_t)(ty * tiles_x + tx) };
+            }
+        }
+        std::sort(d.begin(), d.end());
+        std::vector<uint32_t> order(n);
+        for (size_t i = 0; i < n; i++)
+            order[i] = d[i].second;
+        HIP_TRY(sc.order.reserve(n));
+        HIP_TRY(hipMemcpyAsync(sc.order.p, order.data(), n * 4, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream)); // `order` is a local
+        sc.order_key = key;
+    }
+    cam.order = sc.order.p;
+    return RT_OK;
 }
 
 // Enqueue the whole flattened recursion for n_items rays on `stream`:
@@ -285,8 +331,14 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.parallelogram_n = p.parallelogram_n, a.segment_n = p.segment_n, a.seed = p.seed;
     a.min_waves = (uint32_t)g_min_waves.load();
     a.fused = g_fused.load() ? 1u : 0u;
+    a.prio_levels = g_prio.load() ? 1u : 0u;
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
+    if (source == rt::SRC_CAMERA) {
+        const int rc = tile_order_for(sc, a.cam, stream);
+        if (rc != RT_OK)
+            return rc;
+    }
     a.state = sc.state.p;
     a.n_items = n_items;
     a.counters = counters_dev;
@@ -315,6 +367,22 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
                 sc.events.emplace_back(e0, e1);
             }
             HIP_TRY(hipEventRecord(sc.events[sc.events_used].first, stream));
+        }
+        memset(&a.share, 0, sizeof(a.share));
+        if (a.fused && g_share.load() && n_levels > 1) {
+            // helpers + packets (k_trace_level "Helpers"): every word re-initialised per launch
+            constexpr uint32_t kQueueCap = 1u << 16, kQueueSlack = 1u << 14;
+            HIP_TRY(sc.share_sched.reserve(rt::SH_WORDS));
+            HIP_TRY(sc.share_queue.reserve(kQueueCap + kQueueSlack));
+            HIP_TRY(sc.share_rays.reserve(2 * (size_t)n_items));
+            a.share.sched = sc.share_sched.p;
+            a.share.queue = sc.share_queue.p;
+            a.share.rays = sc.share_rays.p;
+            a.share.queue_cap = kQueueCap;
+            a.share.ray_cap = n_items;
+            a.share.n_groups = rt::trace_level_groups(a);
+            HIP_TRY(hipMemsetAsync(sc.share_sched.p, 0, rt::SH_WORDS * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(sc.share_queue.p, 0, (size_t)(kQueueCap + kQueueSlack) * sizeof(unsigned long long), stream));
         }
         rt::launch_trace_level(a, counters_dev != nullptr, stream);
         if (bvh->profile) {
@@ -395,6 +463,18 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "fused") == 0) { // 1: all recursion levels in one launch (default); 0: one launch per level
         g_fused.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "prio") == 0) { // 1: deeper recursion levels get a higher wave priority (default)
+        g_prio.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "share") == 0) { // 1: tail work sharing between the waves of a fused launch (default)
+        g_share.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "tile_order") == 0) { // 1: centre-first dispatch of the primary tiles (default); 0: row-major
+        g_tile_order.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "super_log") == 0) {
@@ -776,15 +856,22 @@ int rt_debug_div_check(uint32_t seed, uint32_t mode, uint64_t n_samples, uint64_
 }
 
 // Diagnostic (library built with -DRT_STAMPS): zero / read the 24 phase-clock slots.
-int rt_debug_stamps(int reset, unsigned long long* out16)
+// With -DRT_TIMELINE the buffer holds 3 words (start, end, hardware id) for each of
+// up to 2^17 waves of the last k_trace_level launch instead.
+#ifdef RT_TIMELINE
+constexpr size_t kStampWords = 3u << 17;
+#else
+constexpr size_t kStampWords = 24;
+#endif
+int rt_debug_stamps(int reset, unsigned long long* out)
 {
     if (!g_stamps)
-        HIP_TRY(hipMalloc((void**)&g_stamps, 24 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&g_stamps, kStampWords * sizeof(unsigned long long)));
     HIP_TRY(hipDeviceSynchronize());
-    if (out16)
-        HIP_TRY(hipMemcpy(out16, g_stamps, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (out)
+        HIP_TRY(hipMemcpy(out, g_stamps, kStampWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset)
-        HIP_TRY(hipMemset(g_stamps, 0, 24 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_stamps, 0, kStampWords * sizeof(unsigned long long)));
     return RT_OK;
 }
 

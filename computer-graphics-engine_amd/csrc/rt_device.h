@@ -118,6 +118,9 @@ RT_DEV float4 buf_load16(BufRsrc r, uint32_t byte_off)
 struct LaneCounters {
     uint32_t box = 0, tri = 0, sph = 0;     // lane-level tests
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
+#ifdef RT_TIMELINE
+    uint32_t tl_node_iters = 0, tl_leaf_steps = 0, tl_traversals = 0; // wave-uniform step counts (diagnostic)
+#endif
 };
 
 // Per-wave LDS working set (9.4 KiB): ray table, best-key slots, the per-lane

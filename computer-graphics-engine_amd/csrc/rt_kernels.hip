@@ -72,6 +72,8 @@ RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_
     const uint32_t tiles_x = ((uint32_t)c.width + tw - 1u) >> c.tile_wlog;
     uint32_t tx, ty;
     if (c.super_log == 0) {
+        if (c.order)
+            wave = c.order[wave];
         ty = wave / tiles_x, tx = wave - ty * tiles_x;
     } else {
         const uint32_t s = c.super_log, wpb = kBlock / 64;
@@ -130,6 +132,20 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
     }
 }
 
+// agent-scope relaxed accesses to the work-sharing words (one lane)
+RT_DEV uint32_t sh_load(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RT_DEV uint32_t sh_add(uint32_t* p, uint32_t v)
+{
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+RT_DEV uint64_t uni64(uint64_t v)
+{
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+constexpr uint32_t kShareMinRays = 4;      // never split below this many rays per part
+constexpr uint32_t kShareMaxParts = 4;     // one wave hands out at most three packets per level
+constexpr uint32_t kShareSpinLimit = 1u << 18;
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const LevelArgs a)
 {
@@ -179,10 +195,41 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
             pixel = a.in.pixel ? a.in.pixel[i] : i;
         }
     }
-    if (ballot(active) == 0)
+#ifdef RT_TIMELINE // diagnostic: (start, end, HW_ID) of every wave, 100 MHz constant clock
+    const unsigned long long tl_begin = wall_clock64();
+    struct TimelineEnd {
+        unsigned long long* p;
+        unsigned long long t0;
+        uint32_t wave, lane;
+        const LaneCounters* lc;
+        __device__ ~TimelineEnd()
+        {
+            if (p && lane == 0 && wave < (1u << 17)) {
+                uint32_t hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                uint32_t xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                p[3 * (size_t)wave] = t0;
+                p[3 * (size_t)wave + 1] = wall_clock64();
+                // word 2: hw id (16 bits of it) | xcc | node iterations | leaf steps | traversals
+                p[3 * (size_t)wave + 2] = (unsigned long long)((hw >> 8) & 0x3ffu) | ((unsigned long long)(xcc & 0xfu) << 10)
+                    | ((unsigned long long)(lc->tl_node_iters & 0xfffffu) << 14)
+                    | ((unsigned long long)(lc->tl_leaf_steps & 0xfffffu) << 34)
+                    | ((unsigned long long)(lc->tl_traversals & 0x3ffu) << 54);
+            }
+        }
+    } tl_end { a.sv.stamps, tl_begin, wave, lane, nullptr };
+#endif
+    uint32_t* const sched = a.share.sched;
+    if (sched && lane == 0)
+        sh_add(&sched[SH_STARTED0 + (wave & 63u) * SH_SLOT_STRIDE], 1u);
+    if (!sched && ballot(active) == 0)
         return;
 
     LaneCounters lc;
+#ifdef RT_TIMELINE
+    tl_end.lc = &lc;
+#endif
     RayCounts rc;
     if (COUNT && active)
         rc.closest = 1;
@@ -190,7 +237,22 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     WaveLds& wl = lds[threadIdx.x >> 6];
 
     const int32_t first_level = a.level;
-    for (int32_t level = first_level;; level++) {
+    int32_t level = first_level;
+    for (;;) { // work units of this wave: its own tile, then (Helpers) packets of other waves
+    if (ballot(active) != 0)
+    for (;; level++) {
+    // Deeper levels issue first: a tile's path tree is a serial chain of levels, and the
+    // launch ends when the longest chain does.
+    if (a.prio_levels) {
+        if (level <= 0)
+            __builtin_amdgcn_s_setprio(0);
+        else if (level == 1)
+            __builtin_amdgcn_s_setprio(1);
+        else if (level == 2)
+            __builtin_amdgcn_s_setprio(2);
+        else
+            __builtin_amdgcn_s_setprio(3);
+    }
     // ---- closest hit (bvh.intersect, render.cpp:31) -----------------------------
     int32_t pos;
     traverse<false, COUNT>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
@@ -307,6 +369,53 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         // queue, no launch per level, and deep sparse levels overlap with everything else.
         if (smask == 0)
             break;
+        if (sched) { // Helpers are waiting: hand them all but the first part of this wave's rays
+            const uint32_t k = (uint32_t)__builtin_popcountll(smask);
+            uint32_t parts = 1, base = 0;
+            if (k >= 2u * kShareMinRays) {
+                if (lane == 0) {
+                    const uint32_t claim = sh_load(&sched[SH_CLAIM]), alloc = sh_load(&sched[SH_ALLOC]);
+                    if (claim > alloc && alloc + kShareMaxParts < a.share.queue_cap) {
+                        parts = claim - alloc + 1u;
+                        parts = parts < k / kShareMinRays ? parts : k / kShareMinRays;
+                        parts = parts < kShareMaxParts ? parts : kShareMaxParts;
+                        if (parts > 1u) {
+                            const uint32_t chunk = (k + parts - 1u) / parts;
+                            base = sh_add(&sched[SH_RAY_ALLOC], k - chunk);
+                            if (base + (k - chunk) > a.share.ray_cap)
+                                parts = 1u;
+                        }
+                    }
+                }
+                parts = uni(parts), base = uni(base);
+            }
+            if (parts > 1u) {
+                const uint32_t chunk = (k + parts - 1u) / parts;
+                const uint32_t rank = prefix_count(smask);
+                if (spawn && rank >= chunk) {
+                    float4* q = a.share.rays + 2 * (size_t)(base + rank - chunk);
+                    q[0] = make_float4(refl.o.x, refl.o.y, refl.o.z, refl.d.x);
+                    q[1] = make_float4(refl.d.y, refl.d.z, __uint_as_float(item), __uint_as_float(pixel));
+                }
+                // publish: everything this wave stored (rays, state, direct colours) before the descriptors
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    const uint32_t n_packets = (k - chunk + chunk - 1u) / chunk;
+                    sh_add(&sched[SH_CREATED], n_packets);
+                    const uint32_t idx0 = sh_add(&sched[SH_ALLOC], n_packets);
+                    for (uint32_t pk = 0; pk < n_packets; pk++) {
+                        const uint32_t first = chunk * (pk + 1u);
+                        const uint32_t cnt = k - first < chunk ? k - first : chunk;
+                        const unsigned long long desc = (1ull << 63) | ((unsigned long long)(uint32_t)(level + 1) << 40)
+                            | ((unsigned long long)cnt << 32) | (unsigned long long)(base + first - chunk);
+                        if (idx0 + pk < a.share.queue_cap)
+                            __hip_atomic_store(&a.share.queue[idx0 + pk], desc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                spawn = spawn && rank < chunk;
+            }
+        }
         active = spawn;
         ray = refl;
         t = kFltMax;
@@ -332,6 +441,85 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         }
     }
     break;
+    }
+    // ---- Helpers ------------------------------------------------------------------------
+    // A fused launch ends with a few waves still walking their tiles' path trees while most
+    // of the chip is idle (tools/timeline.py). Once every workgroup of the launch has started
+    // (nobody else needs this wave's slot) a finished wave takes a ticket and waits for the
+    // packet with that number; waves that still have rays see tickets outstanding at their
+    // next level boundary and publish parts of their rays as packets. Descriptor words are
+    // written once, by one agent-scope atomic store, after an agent-scope release of the
+    // payload; the helper acquires before reading it. A wave leaves when no work is pending.
+    if (!sched)
+        return;
+    constexpr unsigned long long kExit = 1ull << 62;
+    if (lane == 0)
+        sh_add(&sched[SH_FINISHED0 + (wave & 63u) * SH_SLOT_STRIDE], 1u); // this unit is finished
+    // Has every workgroup of the launch started? (then nobody needs this wave's slot)
+    uint32_t all_started = uni(sh_load(&sched[SH_ALL_STARTED]));
+    if (!all_started && wave + 16384u >= a.share.n_groups) { // only late workgroups can be the first to see it
+        if (wave_sum(sh_load(&sched[SH_STARTED0 + lane * SH_SLOT_STRIDE])) >= a.share.n_groups) {
+            all_started = 1u;
+            if (lane == 0)
+                __hip_atomic_store(&sched[SH_ALL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!all_started)
+        return;
+    // the wave that finishes the LAST unit releases every waiting helper
+    auto all_finished = [&]() {
+        const uint32_t fin = wave_sum(sh_load(&sched[SH_FINISHED0 + lane * SH_SLOT_STRIDE]));
+        return fin >= a.share.n_groups + uni(sh_load(&sched[SH_CREATED]));
+    };
+    if (all_finished()) {
+        const uint32_t claim = uni(sh_load(&sched[SH_CLAIM])), alloc = uni(sh_load(&sched[SH_ALLOC]));
+        for (uint32_t i = alloc + lane; i < claim && i < a.share.queue_cap; i += 64u)
+            __hip_atomic_store(&a.share.queue[i], kExit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    uint32_t ticket = 0;
+    if (lane == 0)
+        ticket = sh_add(&sched[SH_CLAIM], 1u);
+    ticket = uni(ticket);
+    if (ticket >= a.share.queue_cap)
+        return;
+    // Poll only this ticket's own word (one waiter per word). The finished counts are summed
+    // rarely, as a backstop for a helper that took its ticket while the last finisher was
+    // already handing out exits.
+    unsigned long long desc = 0;
+    for (uint32_t spins = 0;; spins++) {
+        desc = uni64(__hip_atomic_load(&a.share.queue[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (desc != 0)
+            break;
+        if ((spins & 63u) == 0u && all_finished())
+            break;
+        if (spins > kShareSpinLimit) { // never expected: report instead of hanging
+            if (lane == 0)
+                __hip_atomic_store(&sched[SH_ERROR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        const uint32_t naps = spins < 4u ? 1u : (spins < 16u ? 2u : 4u);
+        for (uint32_t i = 0; i < naps; i++)
+            __builtin_amdgcn_s_sleep(127);
+    }
+    if (desc == kExit)
+        desc = 0;
+    if (desc == 0)
+        return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t cnt = (uint32_t)(desc >> 32) & 0xffu, base = (uint32_t)desc;
+    level = (int32_t)((desc >> 40) & 0xffu);
+    active = lane < cnt;
+    t = kFltMax;
+    if (active) {
+        const float4* q = a.share.rays + 2 * (size_t)(base + lane);
+        const float4 q0 = q[0], q1 = q[1];
+        ray.o = mk(q0.x, q0.y, q0.z);
+        ray.d = mk(q0.w, q1.x, q1.y);
+        item = __float_as_uint(q1.z), pixel = __float_as_uint(q1.w);
+    }
+    if (COUNT && active)
+        rc.closest = 1;
     }
 }
 
@@ -527,6 +715,18 @@ uint64_t camera_waves(const CameraArgs& c)
 void set_diag_leaf(const float4* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_leaf), &p, sizeof(p)); }
 #endif
 uint32_t g_lds_pad = 0; // tuning experiment: extra dynamic LDS per block lowers occupancy
+
+uint32_t trace_level_groups(const LevelArgs& a)
+{
+    uint64_t waves;
+    if (a.source == SRC_CAMERA)
+        waves = camera_waves(a.cam);
+    else if (a.source == SRC_QUEUE)
+        waves = ((uint64_t)a.in.cap + 63) / 64;
+    else
+        waves = ((uint64_t)a.in_count_imm + 63) / 64;
+    return waves ? grid_for_waves(waves) : 0u;
+}
 
 void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
 {

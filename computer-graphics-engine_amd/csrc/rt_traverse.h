@@ -121,6 +121,9 @@ RT_DEV void leaf_phase(WaveLds& L, BufRsrc leaf, bool spheres, uint32_t first, u
     LeafSlot cur, nxt;
     leaf_fetch<ANY>(L, leaf, my_ref, my_rc, my_lb, prune, 0u, n, upper, sub, cur);
     for (uint32_t k = 0; k < n; k += 2) {
+#ifdef RT_TIMELINE
+        lc.tl_leaf_steps++;
+#endif
         nxt.live = false;
         nxt.cmax = 0;
         if (k + 2 < n)
@@ -239,6 +242,9 @@ struct Walk {
             const uint64_t busy = ballot(sp > bot);
             if (busy == 0)
                 break;
+#ifdef RT_TIMELINE
+            lc.tl_node_iters++;
+#endif
 #ifdef RT_STAMPS
             const unsigned long long ts0 = clock64();
 #endif
@@ -378,6 +384,9 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     const uint64_t act = ballot(active);
     if (act == 0)
         return;
+#ifdef RT_TIMELINE
+    lc.tl_traversals++;
+#endif
     const uint32_t lane = lane_id();
     prune = prune && use_bvh && sv.prune_ok != 0u;
     L.rayA[lane] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
