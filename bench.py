@@ -41,13 +41,14 @@ STRIP_ROWS = 8
 
 
 def algorithmic_bytes(cnt: dict, features, pixels: int) -> dict:
-    """32 B per box test (24 B AABB + 8 B child meta), 36 B per
+    """32 B per box test (24 B AABB + 8 B child meta; the leaf
+    phase's triangle-group boxes are box tests too), 36 B per
     triangle test (three fp32 positions), 16 B per sphere test; per shaded hit
     32 B material (+36 B normals with normalInterp, +24 B uvs +12 B texel with
     textures) and its 12 B direct-colour write; 2 x 32 B per queued reflection ray
     (written by one level, read by the next); 12 B per pixel for the frame write
     (k_fold, not part of the trace kernel's figure)."""
-    trav = 32 * cnt["box_tests"] + 36 * cnt["tri_tests"] + 16 * cnt["sphere_tests"]
+    trav = 32 * (cnt["box_tests"] + cnt.get("group_tests", 0)) + 36 * cnt["tri_tests"] + 16 * cnt["sphere_tests"]
     per_hit = 32 + 12 + (36 if features.enableNormalInterp else 0) + (36 if features.enableTextureMapping else 0)
     shade = per_hit * cnt["hits_shaded"]
     queue = 64 * cnt["rays_queued"]
@@ -186,7 +187,7 @@ def main():
                        "rays_per_frame": rays_per_frame, "rays_reference_equivalent": total["rays_ref_equiv"],
                        "rays_primary": total["rays_primary"], "rays_shadow": total["rays_shadow"],
                        "rays_reflect": total["rays_reflect"], "box_tests": total["box_tests"],
-                       "tri_tests": total["tri_tests"], "node_fetches": total["node_fetches"],
+                       "tri_tests": total["tri_tests"], "group_tests": total.get("group_tests", 0), "node_fetches": total["node_fetches"],
                        "tri_fetches": total["tri_fetches"], "algorithmic_bytes_per_frame": ab["frame"],
                        "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather(overlapped)" if world > 1 else "")
                        + ("+REHEARSAL-gloo-one-device" if rehearsal else ""),

@@ -11,6 +11,7 @@
 #include "host_scene.h"
 
 #include <algorithm>
+#include <limits>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -323,11 +324,90 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
             pair_of[i] = (int32_t)pairs.size();
             pairs.emplace_back();
         }
+    // Culling groups of the leaves (rt_layout.h GroupRecord): triangles only, <= 32 per leaf
+    groups.clear();
+    grouped_src.clear();
+    std::vector<uint32_t> leaf_group_beg(nodes.size(), 0xffffffffu);
+    if (scene.spheres.empty()) {
+        struct Tri {
+            float c[3];
+            uint32_t rank;
+        };
+        std::vector<Tri> tri;
+        // order a leaf's triangles so that consecutive runs of four are spatially compact:
+        // recursive median split of the centroids along their longest axis, cut at a multiple of 4
+        auto order = [&](auto&& self, Tri* a, uint32_t cnt) -> void {
+            if (cnt <= 4)
+                return;
+            float lo[3] = { a[0].c[0], a[0].c[1], a[0].c[2] }, hi[3] = { lo[0], lo[1], lo[2] };
+            for (uint32_t i = 1; i < cnt; i++)
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = std::min(lo[k], a[i].c[k]);
+                    hi[k] = std::max(hi[k], a[i].c[k]);
+                }
+            int ax = 0;
+            for (int k = 1; k < 3; k++)
+                if (hi[k] - lo[k] > hi[ax] - lo[ax])
+                    ax = k;
+            const uint32_t mid = ((cnt / 2 + 3) / 4) * 4; // 4 <= mid < cnt for cnt >= 5
+            std::nth_element(a, a + mid, a + cnt, [ax](const Tri& x, const Tri& y) {
+                return x.c[ax] < y.c[ax] || (x.c[ax] == y.c[ax] && x.rank < y.rank);
+            });
+            self(self, a, mid);
+            self(self, a + mid, cnt - mid);
+        };
+        for (size_t i = 0; i < nodes.size(); i++) {
+            const RefNode& nd = nodes[i];
+            const uint32_t cnt = nd.leaf ? (uint32_t)(nd.end - nd.beg) : 0u;
+            if (!nd.leaf || cnt == 0 || cnt > kGroupLeafMax)
+                continue;
+            const uint32_t ref = leaf_dev_beg[i];
+            tri.resize(cnt);
+            for (uint32_t k = 0; k < cnt; k++) {
+                const PrimRecord& r = this->records[ref + k];
+                for (int a = 0; a < 3; a++)
+                    tri[k].c[a] = (r.v0[a] + r.v1[a] + r.v2[a]) * (1.0f / 3.0f);
+                tri[k].rank = k;
+            }
+            order(order, tri.data(), cnt);
+            if (groups.size() + (cnt + 3) / 4 >= (1u << 25))
+                break; // count word holds 25 bits of group index: the rest stays ungrouped
+            leaf_group_beg[i] = (uint32_t)groups.size();
+            for (uint32_t g = 0; g * 4 < cnt; g++) {
+                GroupRecord gr;
+                memset(&gr, 0, sizeof(gr));
+                for (int a = 0; a < 3; a++)
+                    gr.lo[a] = std::numeric_limits<float>::infinity(), gr.hi[a] = -std::numeric_limits<float>::infinity();
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t k = g * 4 + j;
+                    if (k >= cnt) {
+                        gr.ranks |= 31u << (5 * j);
+                        grouped_src.push_back(0xffffffffu);
+                        continue;
+                    }
+                    const PrimRecord& r = this->records[ref + tri[k].rank];
+                    for (int a = 0; a < 3; a++) {
+                        gr.lo[a] = std::min(gr.lo[a], std::min(r.v0[a], std::min(r.v1[a], r.v2[a])));
+                        gr.hi[a] = std::max(gr.hi[a], std::max(r.v0[a], std::max(r.v1[a], r.v2[a])));
+                    }
+                    gr.ranks |= tri[k].rank << (5 * j);
+                    grouped_src.push_back(ref + tri[k].rank);
+                }
+                groups.push_back(gr);
+            }
+        }
+    }
+    if (groups.empty()) { // keep the device arrays non-empty
+        groups.emplace_back();
+        grouped_src.assign(4, 0xffffffffu);
+    }
     auto child_ref = [&](int32_t node, uint32_t& ref, uint32_t& cnt) {
         const RefNode& c = nodes[node];
-        if (c.leaf)
-            ref = leaf_dev_beg[node], cnt = (uint32_t)(c.end - c.beg);
-        else
+        if (c.leaf) {
+            ref = leaf_dev_beg[node];
+            const uint32_t n_leaf = (uint32_t)(c.end - c.beg);
+            cnt = leaf_group_beg[node] != 0xffffffffu ? (n_leaf | (leaf_group_beg[node] << 6)) : (0x80000000u | n_leaf);
+        } else
             ref = (uint32_t)pair_of[node], cnt = 0;
     };
     for (size_t i = 0; i < nodes.size(); i++) {
@@ -341,6 +421,8 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
         child_ref(nodes[i].right, p.r_ref, p.r_cnt);
     }
     child_ref(root, root_ref, root_cnt);
+    if (root_cnt != 0u) // a root that is a leaf takes the ungrouped path (one range per ray)
+        root_cnt = 0x80000000u | (uint32_t)(nodes[root].end - nodes[root].beg);
     bounds_finite = true;
     for (const NodePair& p : pairs)
         for (int a = 0; a < 3; a++)

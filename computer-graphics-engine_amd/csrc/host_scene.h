@@ -53,7 +53,11 @@ struct HostBvh {
     bool bounds_finite = true;       // every bound of every pair is a finite float
     std::vector<PrimRecord> records;      // the reference's visit order (leaves right-first) — BVH mode
     std::vector<PrimRecord> records_flat; // the reference's array order — brute-force mode
-    uint32_t root_ref = 0, root_cnt = 0;
+    // culling groups (rt_layout.h GroupRecord): slot i of the grouped leaf array holds
+    // records[grouped_src[i]] (0xffffffff = padding)
+    std::vector<GroupRecord> groups;
+    std::vector<uint32_t> grouped_src;
+    uint32_t root_ref = 0, root_cnt = 0; // root_cnt: count word (rt_layout.h)
     int num_levels = 0, num_leaves = 0;
     uint32_t max_leaf = 0;
 

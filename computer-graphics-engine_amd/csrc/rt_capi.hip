@@ -132,7 +132,8 @@ struct rt_bvh {
     rt::HostBvh host;
     DevBuf<rt::NodePair> nodes;
     DevBuf<rt::PrimRecord> prims, prims_flat;
-    DevBuf<rt::LeafRecord> leaf, leaf_flat;
+    DevBuf<rt::LeafRecord> leaf, leaf_flat, leaf_grouped;
+    DevBuf<rt::GroupRecord> groups;
 #ifdef RT_DIAG
     DevBuf<rt::NodePair> diag_nodes;
     DevBuf<rt::LeafRecord> diag_leaf;
@@ -156,6 +157,9 @@ struct rt_bvh {
         v.prims_flat = prims_flat.p;
         v.leaf = reinterpret_cast<const float4*>(leaf.p);
         v.leaf_flat = reinterpret_cast<const float4*>(leaf_flat.p);
+        v.leaf_grouped = reinterpret_cast<const float4*>(leaf_grouped.p);
+        v.groups = reinterpret_cast<const float4*>(groups.p);
+        v.n_groups = (uint32_t)host.groups.size();
         v.tri_vidx = scene->tri_vidx.p;
         v.vnormal = scene->vnormal.p;
         v.vtexcoord = scene->vtexcoord.p;
@@ -569,6 +573,16 @@ int rt_bvh_build(rt_scene* scene, const rt_features* features, rt_bvh** out)
     HIP_TRY(b->prims_flat.upload(b->host.records_flat));
     HIP_TRY(b->leaf.upload(leaf_records(b->host.records)));
     HIP_TRY(b->leaf_flat.upload(leaf_records(b->host.records_flat)));
+    {
+        std::vector<rt::PrimRecord> g(b->host.grouped_src.size());
+        for (size_t i = 0; i < g.size(); i++)
+            if (b->host.grouped_src[i] != 0xffffffffu)
+                g[i] = b->host.records[b->host.grouped_src[i]];
+            else
+                memset(&g[i], 0, sizeof(g[i]));
+        HIP_TRY(b->leaf_grouped.upload(leaf_records(g)));
+        HIP_TRY(b->groups.upload(b->host.groups));
+    }
 #ifdef RT_DIAG
     HIP_TRY(b->diag_nodes.upload(b->host.pairs));
     HIP_TRY(b->diag_leaf.upload(leaf_records(b->host.records)));

@@ -117,6 +117,7 @@ RT_DEV float4 buf_load16(BufRsrc r, uint32_t byte_off)
 
 struct LaneCounters {
     uint32_t box = 0, tri = 0, sph = 0;     // lane-level tests
+    uint32_t grp = 0;                       // lane-level group-box tests (leaf phase)
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
 #ifdef RT_TIMELINE
     uint32_t tl_node_iters = 0, tl_leaf_steps = 0, tl_traversals = 0; // wave-uniform step counts (diagnostic)
@@ -136,11 +137,12 @@ struct alignas(16) WaveLds {
     unsigned long long best[64];
     uint32_t stack[kStackLevels][64]; // packed entries, see pack_entry()
     uint32_t lq_ref[kLeafQueue];
-    uint32_t lq_rc[kLeafQueue]; // ray slot (6 bits) | count << 6
+    uint32_t lq_cw[kLeafQueue]; // count word of the leaf (rt_layout.h); lq_ref holds ref | ray slot << 26
     float lq_lb[kLeafQueue];
     uint32_t xfer[64];          // work-stealing hand-over slots
+    uint32_t surv[80];          // leaf phase: surviving (pair, group) entries, < 16 left over + 64 new
 };
-static_assert(sizeof(WaveLds) == 9664, "WaveLds"); // one wave per workgroup: 16 of them fit a CU's 160 KiB
+static_assert(sizeof(WaveLds) == 9984, "WaveLds"); // one wave per workgroup: 16 of them fit a CU's 160 KiB
 
 // A deque entry in 32 bits: [31:21] lower bound, [20:6] node pair index, [5:0] ray slot.
 // MAX_DEPTH = 16 levels caps a tree at 32 767 internal nodes (15 bits). The bound keeps

@@ -112,7 +112,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
     const uint32_t box = wave_sum(lc.box), tri = wave_sum(lc.tri), sph = wave_sum(lc.sph);
     const uint32_t closest = wave_sum(rc.closest), shadow = wave_sum(rc.shadow);
     const uint32_t hits = wave_sum(rc.hits), queued = wave_sum(rc.queued);
-    const uint32_t node_fetch = wave_sum(lc.node_fetch), tri_fetch = wave_sum(lc.tri_fetch);
+    const uint32_t node_fetch = wave_sum(lc.node_fetch), tri_fetch = wave_sum(lc.tri_fetch), grp = wave_sum(lc.grp);
     if (lane == 0) {
         auto add = [](uint64_t* p, uint64_t v) {
             if (v)
@@ -129,6 +129,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
         add(&out->tri_fetches, tri_fetch);
         add(&out->hits_shaded, hits);
         add(&out->rays_queued, queued);
+        add(&out->group_tests, grp);
     }
 }
 

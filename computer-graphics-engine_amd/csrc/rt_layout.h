@@ -12,6 +12,12 @@
 
 namespace rt {
 
+#if defined(__HIPCC__)
+#define RT_LAYOUT_FN __host__ __device__ inline
+#else
+#define RT_LAYOUT_FN inline
+#endif
+
 // Children of one internal node (src/bounding_volume_hierarchy.cpp:331-355 reads
 // nodes[left].aabb and nodes[right].aabb of the popped parent). Child reference:
 // cnt == 0 → internal node, ref = index of ITS NodePair; cnt > 0 → leaf holding
@@ -64,6 +70,32 @@ struct alignas(16) LeafRecord {
 };
 static_assert(sizeof(LeafRecord) == 48, "LeafRecord must be 48 bytes");
 
+// Culling groups inside a leaf. The reference's leaves hold up to MAX-depth-limited runs of
+// primitives (25 on the bench scene) and its traversal tests every one of them. In the
+// pruned policy the leaf phase first tests the ray against the bounds of GROUPS of four
+// leaf triangles (conservatively, grown by the pruning slack — rt_device.h "Pruning": a
+// candidate's point lies within rho of its triangle, hence of the group's box) and runs the
+// exact triangle test only for the groups it may touch. The leaf's triangles are re-ordered
+// into spatially compact groups (host_scene.cpp), so each slot carries its RANK in the
+// reference's order: keys and reported indices use leaf_ref + rank, which keeps the
+// "tested later wins ties" rule intact. 32 bytes per group.
+struct alignas(16) GroupRecord {
+    float lo[3], hi[3];
+    uint32_t ranks; // four 5-bit ranks (slot j at bits 5j..5j+4), 31 = empty slot
+    uint32_t pad;
+};
+static_assert(sizeof(GroupRecord) == 32, "GroupRecord must be 32 bytes");
+constexpr uint32_t kGroupLeafMax = 32; // leaves with more primitives (or spheres) are not grouped
+
+// Child count word of a NodePair / the root reference:
+//   0                      internal node (ref = NodePair index)
+//   bit 31 set             ungrouped leaf: count = word & 0x7fffffff, primitives leaf[ref .. ref + count)
+//   otherwise              grouped leaf: count = word & 63 (1..32), first group = word >> 6;
+//                          group g covers slots (first + g) * 4 + [0, 4) of leaf_grouped
+RT_LAYOUT_FN bool cw_is_leaf(uint32_t w) { return w != 0u; }
+RT_LAYOUT_FN bool cw_is_big(uint32_t w) { return (w >> 31) != 0u; }
+RT_LAYOUT_FN uint32_t cw_big_count(uint32_t w) { return w & 0x7fffffffu; }
+
 // Material slot (framework mesh.h:22-34 without the shared_ptr)
 struct alignas(16) MaterialRec {
     float kd[3];
@@ -96,6 +128,9 @@ struct SceneView {
     // LeafRecord arrays in the same two orders, as three 16-byte words per primitive
     const float4* leaf;
     const float4* leaf_flat;
+    const float4* leaf_grouped; // LeafRecords in group order (4 slots per group, padded)
+    const float4* groups;       // GroupRecord array, two 16-byte words each
+    uint32_t n_groups;
     const uint32_t* tri_vidx;   // prim_id*3 → global vertex index (triangles only)
     const float* vnormal;       // global vertex normals, xyz
     const float* vtexcoord;     // global vertex texcoords, uv

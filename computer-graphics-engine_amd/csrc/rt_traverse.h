@@ -13,9 +13,10 @@
 //    (A wave-level "packet" walk with scalar node loads was measured too: on the
 //    819 200-triangle bench scene it is 2.5x slower — its visits form one serial
 //    chain per wave — and was dropped; profiles/r01_notes.md.)
-//  LEAF phase. Leaf children are parked as (ray, leaf) pairs in a per-wave queue;
-//    half a wave tests one pair, one primitive per lane (three 16-byte loads of its
-//    48-byte LeafRecord), the next pair's records are prefetched.
+//  LEAF phase. Leaf children are parked as (ray, leaf) pairs in a per-wave queue. A flush
+//    first tests the ray against the bounds of the leaf's GROUPS of four triangles (eight
+//    lanes per pair, conservative, pruned policy only), then runs the exact triangle test
+//    on the surviving groups, four lanes each (rt_layout.h GroupRecord).
 #pragma once
 #include "rt_device.h"
 
@@ -25,54 +26,17 @@ namespace rt {
 #if defined(RT_DIAG) && RT_DIAG == 2
 __device__ const float4* g_diag_leaf;
 #endif
-struct LeafSlot {
-    float4 c[3];                // the primitive's LeafRecord, 16 bytes at a time
-    uint32_t r, ref, cnt, cmax; // ray slot, first primitive, this half's count, max of both halves
-    bool live;                  // this lane holds a record of the first 32 primitives
-};
 
-// the three 16-byte words of primitive (ref + i)
-RT_DEV void load_leaf(BufRsrc leaf, uint32_t ref, uint32_t i, float4 c[3])
+// the three 16-byte words of LeafRecord number `slot`
+RT_DEV void load_leaf(BufRsrc leaf, uint32_t slot, float4 c[3])
 {
-    const uint32_t off = (ref + i) * 48u;
+    const uint32_t off = slot * 48u;
 #pragma unroll
     for (int k = 0; k < 3; k++)
         c[k] = buf_load16(leaf, off + 16u * k);
 }
 
-template <bool ANY>
-RT_DEV void leaf_fetch(const WaveLds& L, BufRsrc leaf, uint32_t my_ref, uint32_t my_rc,
-    float my_lb, bool prune, uint32_t k, uint32_t n, bool upper, uint32_t sub, LeafSlot& s)
-{
-    const uint32_t ref0 = read_lane(my_ref, k), rc0 = read_lane(my_rc, k);
-    const uint32_t k1 = k + 1 < n ? k + 1 : k;
-    const uint32_t ref1 = read_lane(my_ref, k1), rc1 = (k + 1 < n) ? read_lane(my_rc, k1) : 0u;
-    const float lb0 = __uint_as_float(read_lane(__float_as_uint(my_lb), k));
-    const float lb1 = __uint_as_float(read_lane(__float_as_uint(my_lb), k1));
-    s.ref = upper ? ref1 : ref0;
-    const uint32_t rc = upper ? rc1 : rc0;
-    const float lb = upper ? lb1 : lb0;
-    s.r = rc & 63u;
-    const uint32_t cnt_all = rc >> 6;
-    s.cnt = cnt_all;
-    if (ANY ? (L.best[s.r] != kNoHit) : (prune && lb > ray_limit(L, s.r)))
-        s.cnt = 0; // blocked shadow ray / leaf that cannot hold the closest candidate any more
-    // wave-uniform loop bound for leaves with more than 32 primitives
-    const uint32_t c_lo = read_lane(s.cnt, 0), c_hi = read_lane(s.cnt, 32);
-    s.cmax = c_lo > c_hi ? c_lo : c_hi;
-    s.live = sub < s.cnt;
-    if (s.live)
-        load_leaf(leaf, s.ref, sub, s.c);
-#if defined(RT_DIAG) && RT_DIAG == 2 // the same three loads from a second copy of the leaf array
-    if (s.live) {
-        float4 d[3];
-        load_leaf(make_rsrc(g_diag_leaf, 0x7fffffffu), s.ref, sub, d);
-        asm volatile("" ::"v"(d[0].x), "v"(d[1].y), "v"(d[2].z));
-    }
-#endif
-    s.cnt = s.cnt ? cnt_all : 0u;
-}
-
+// one primitive against ray slot r; `index` = its position in the reference's order (key, report)
 template <bool COUNT>
 RT_DEV void leaf_test_one(WaveLds& L, const float4 c[3], uint32_t r, uint32_t index, bool spheres, LaneCounters& lc)
 {
@@ -102,45 +66,116 @@ RT_DEV void leaf_test_one(WaveLds& L, const float4 c[3], uint32_t r, uint32_t in
         atomicMin(&L.best[r], make_key(tt, index, sphere));
 }
 
-// Entries [first, first + n) of the wave's leaf queue, n <= 64: two entries per
-// step, one per half-wave, one primitive per lane; the fetch of step k+1 is issued
-// before step k is tested.
+// Ungrouped range [ref, ref + cnt) of `leaf` against ray slot r, the whole wave on it, one
+// primitive per lane: leaves above kGroupLeafMax primitives, scenes with spheres, a root that
+// is a leaf, and the brute-force mode (enableAccelStructure off: the whole array).
 template <bool ANY, bool COUNT>
-RT_DEV void leaf_phase(WaveLds& L, BufRsrc leaf, bool spheres, uint32_t first, uint32_t n,
-    uint32_t lane, bool prune, LaneCounters& lc)
+RT_DEV void flat_range(WaveLds& L, BufRsrc leaf, bool spheres, uint32_t r, uint32_t ref, uint32_t cnt, uint32_t lane,
+    LaneCounters& lc)
 {
-    uint32_t my_ref = 0, my_rc = 0;
-    float my_lb = 0.0f;
-    if (lane < n) {
-        my_ref = L.lq_ref[first + lane];
-        my_rc = L.lq_rc[first + lane];
-        my_lb = L.lq_lb[first + lane];
+    for (uint32_t base = 0; base < cnt; base += 64u) {
+        if (ANY && L.best[r] != kNoHit)
+            break;
+        const uint32_t i = base + lane;
+        if (i < cnt) {
+            float4 c[3];
+            load_leaf(leaf, ref + i, c);
+            leaf_test_one<COUNT>(L, c, r, ref + i, spheres, lc);
+        }
+        wave_lds_fence();
     }
-    const bool upper = lane >= 32u;
-    const uint32_t sub = lane & 31u;
-    LeafSlot cur, nxt;
-    leaf_fetch<ANY>(L, leaf, my_ref, my_rc, my_lb, prune, 0u, n, upper, sub, cur);
-    for (uint32_t k = 0; k < n; k += 2) {
+}
+
+// Conservative ray / group-box overlap: may the ray pass within the pruning slack of the box
+// at a distance in [0, lim]? Quotients by reciprocal multiplication (<= 1.5 ulp off), every
+// bound moved outward by 2^-20 relative and by the slack; any NaN compares false = "keep".
+RT_DEV bool group_may_hit(float4 g0, float4 g1, float4 ra, float4 rb, float4 rc, float lim)
+{
+    const float tl0 = (g0.x - ra.x) * rc.x, th0 = (g0.w - ra.x) * rc.x;
+    const float tl1 = (g0.y - ra.y) * rc.y, th1 = (g1.x - ra.y) * rc.y;
+    const float tl2 = (g0.z - ra.z) * rc.z, th2 = (g1.y - ra.z) * rc.z;
+    const float tin = fmaxf(fmaxf(fminf(tl0, th0), fminf(tl1, th1)), fminf(tl2, th2));
+    const float tout = fminf(fminf(fmaxf(tl0, th0), fmaxf(tl1, th1)), fmaxf(tl2, th2));
+    const float lo = tin - fabsf(tin) * 9.5367431640625e-07f - rc.w;
+    const float hi = tout + fabsf(tout) * 9.5367431640625e-07f + rc.w;
+    return !(lo > hi) && !(hi < 0.0f) && !(lo > lim);
+}
+
+// Entries [first, first + n) of the wave's leaf queue (grouped leaves only).
+//  Stage A: 8 lanes per (ray, leaf) pair, one GROUP of four triangles per lane: conservative
+//           box test (pruned policy), survivors appended to an LDS list together with the
+//           group's four ranks.
+//  Stage B: 4 lanes per surviving group, one triangle per lane: the reference's exact test.
+template <bool ANY, bool COUNT>
+RT_DEV void leaf_phase(WaveLds& L, BufRsrc leafg, BufRsrc groups, uint32_t first, uint32_t n, uint32_t lane, bool prune,
+    LaneCounters& lc)
+{
+    auto stage_b = [&](uint32_t base, uint32_t take) {
+        const uint32_t s = lane >> 2, j = lane & 3u;
+        if (s < take) {
+            const uint32_t e = L.surv[base + s];
+            const uint32_t rank = (e >> (11u + 5u * j)) & 31u;
+            const uint32_t pi = (e >> 3) & 0xffu, g = e & 7u;
+            const uint32_t refw = L.lq_ref[pi], cw = L.lq_cw[pi];
+            const uint32_t r = refw >> 26;
+            if (rank != 31u && !(ANY && L.best[r] != kNoHit)) {
+                float4 c[3];
+                load_leaf(leafg, ((cw >> 6) + g) * 4u + j, c);
+#if defined(RT_DIAG) && RT_DIAG == 2 // the same three loads from a second copy of the leaf array
+                {
+                    float4 dd[3];
+                    load_leaf(make_rsrc(g_diag_leaf, 0x7fffffffu), ((cw >> 6) + g) * 4u + j, dd);
+                    asm volatile("" ::"v"(dd[0].x), "v"(dd[1].y), "v"(dd[2].z));
+                }
+#endif
+                leaf_test_one<COUNT>(L, c, r, (refw & 0x3ffffffu) + rank, false, lc);
+            }
+        }
 #ifdef RT_TIMELINE
         lc.tl_leaf_steps++;
 #endif
-        nxt.live = false;
-        nxt.cmax = 0;
-        if (k + 2 < n)
-            leaf_fetch<ANY>(L, leaf, my_ref, my_rc, my_lb, prune, k + 2, n, upper, sub, nxt);
-        if (cur.live)
-            leaf_test_one<COUNT>(L, cur.c, cur.r, cur.ref + sub, spheres, lc);
-        // leaves larger than 32 primitives (brute-force mode, very large meshes)
-        for (uint32_t base = 32u; base < cur.cmax; base += 32u) {
-            const uint32_t idx = base + sub;
-            if (idx < cur.cnt && !(ANY && L.best[cur.r] != kNoHit)) {
-                float4 c[3];
-                load_leaf(leaf, cur.ref, idx, c);
-                leaf_test_one<COUNT>(L, c, cur.r, cur.ref + idx, spheres, lc);
+        wave_lds_fence();
+    };
+    uint32_t fill = 0;
+    for (uint32_t k = 0; k < n; k += 8u) {
+        const uint32_t p = k + (lane >> 3), g = lane & 7u;
+        bool alive = false;
+        uint32_t entry = 0;
+        if (p < n) {
+            const uint32_t refw = L.lq_ref[first + p], cw = L.lq_cw[first + p];
+            const float lb = L.lq_lb[first + p];
+            const uint32_t r = refw >> 26;
+            const float lim = ANY ? L.rayB[r].z : ray_limit(L, r);
+            const bool skip = ANY ? (L.best[r] != kNoHit) : (prune && lb > lim);
+            if (g * 4u < (cw & 63u) && !skip) {
+                const uint32_t off = ((cw >> 6) + g) * 32u;
+                const float4 g0 = buf_load16(groups, off), g1 = buf_load16(groups, off + 16u);
+                alive = true;
+                if (prune) {
+                    const float4 rb = L.rayB[r];
+                    if (__float_as_uint(rb.w) & 8u) // reciprocals usable on all three axes, finite origin
+                        alive = group_may_hit(g0, g1, L.rayA[r], rb, L.rayC[r], lim);
+                    if (COUNT)
+                        lc.grp++;
+                }
+                entry = ((first + p) << 3) | g | (__float_as_uint(g1.z) << 11);
             }
         }
-        cur = nxt;
+        const uint64_t m = ballot(alive);
+        if (alive)
+            L.surv[fill + prefix_count(m)] = entry;
+        fill += (uint32_t)__builtin_popcountll(m);
+#ifdef RT_TIMELINE
+        lc.tl_leaf_steps++;
+#endif
+        wave_lds_fence();
+        while (fill >= 16u) {
+            fill -= 16u;
+            stage_b(fill, 16u);
+        }
     }
+    if (fill)
+        stage_b(0u, fill);
 }
 
 // State shared by the engines of one traverse() call.
@@ -148,7 +183,8 @@ template <bool ANY, bool COUNT>
 struct Walk {
     const SceneView& sv;
     WaveLds& L;
-    BufRsrc leaf, nodes; // LeafRecord / NodePair arrays
+    BufRsrc leaf, nodes; // ungrouped LeafRecord array (visit or array order) / NodePair array
+    BufRsrc leafg, groups; // grouped LeafRecord array / GroupRecord array
     bool spheres; // the scene holds spheres (wave-uniform)
     LaneCounters& lc;
     uint32_t lane;
@@ -175,15 +211,30 @@ struct Walk {
         }
     }
 
-    // append the lanes' (ray r, leaf ref/cnt, lb) pairs for which `want` is set
-    RT_DEV void queue_leaves(bool want, uint32_t r, uint32_t ref, uint32_t cnt, float lb)
+    // append the lanes' (ray r, leaf ref / count word, lb) pairs for which `want` is set;
+    // ungrouped leaves (rt_layout.h count word) are tested at once, the whole wave on each
+    RT_DEV void queue_leaves(bool want, uint32_t r, uint32_t ref, uint32_t cw, float lb)
     {
+        uint64_t big = ballot(want && cw_is_big(cw));
+        if (big) {
+            wave_lds_fence();
+            while (big) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(big);
+                big &= big - 1;
+                const uint32_t rr = read_lane(r, src), bref = read_lane(ref, src), bcnt = cw_big_count(read_lane(cw, src));
+                const float blb = __uint_as_float(read_lane(__float_as_uint(lb), src));
+                if (ANY ? (L.best[rr] != kNoHit) : (prune && blb > ray_limit(L, rr)))
+                    continue;
+                flat_range<ANY, COUNT>(L, leaf, spheres, rr, bref, bcnt, lane, lc);
+            }
+            want = want && !cw_is_big(cw);
+        }
         const uint64_t m = ballot(want);
         if (m) {
             if (want) {
                 const uint32_t o = lq_n + prefix_count(m);
-                L.lq_ref[o] = ref;
-                L.lq_rc[o] = r | (cnt << 6);
+                L.lq_ref[o] = ref | (r << 26);
+                L.lq_cw[o] = cw;
                 L.lq_lb[o] = lb;
             }
             lq_n += (uint32_t)__builtin_popcountll(m);
@@ -202,7 +253,7 @@ struct Walk {
             while (lq_n > 0u) {
                 const uint32_t n = lq_n < 64u ? lq_n : 64u;
                 lq_n -= n;
-                leaf_phase<ANY, COUNT>(L, leaf, spheres, lq_n, n, lane, prune, lc);
+                leaf_phase<ANY, COUNT>(L, leafg, groups, lq_n, n, lane, prune, lc);
             }
             wave_lds_fence();
 #ifdef RT_STAMPS
@@ -350,7 +401,7 @@ struct Walk {
                         L.stack[row0 + sp][lane] = l_far ? e_r : e_l;
                         sp++;
                     }
-                    leaf_l = hl && l_cnt != 0u;
+                    leaf_l = hl && l_cnt != 0u; // l_cnt / r_cnt: count words (rt_layout.h)
                     leaf_r = hr && r_cnt != 0u;
 #ifdef RT_STAMPS
                     st_push += clock64() - ta;
@@ -395,13 +446,14 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     L.rayC[lane] = make_float4(inv.y[0], inv.y[1], inv.y[2], inv.slack);
     L.best[lane] = kNoHit;
     Walk<ANY, COUNT> w { sv, L, make_rsrc(use_bvh ? sv.leaf : sv.leaf_flat, sv.n_prims * 48u),
-        make_rsrc(sv.nodes, sv.n_pairs * 64u), sv.prune_ok == 0u, lc, lane, prune, 0u, ray, inv, lane };
+        make_rsrc(sv.nodes, sv.n_pairs * 64u), make_rsrc(sv.leaf_grouped, sv.n_groups * 4u * 48u),
+        make_rsrc(sv.groups, sv.n_groups * 32u), sv.prune_ok == 0u, lc, lane, prune, 0u, ray, inv, lane };
 #ifdef RT_STAMPS
     const unsigned long long stamp_begin = clock64();
 #endif
 
-    if (!use_bvh || sv.root_cnt != 0u) // the root is a leaf / brute force: one pair per ray
-        w.queue_leaves(active, lane, use_bvh ? sv.root_ref : 0u, use_bvh ? sv.root_cnt : sv.n_prims, 0.0f);
+    if (!use_bvh || sv.root_cnt != 0u) // the root is a leaf / brute force: one ungrouped range per ray
+        w.queue_leaves(active, lane, use_bvh ? sv.root_ref : 0u, use_bvh ? sv.root_cnt : (0x80000000u | sv.n_prims), 0.0f);
     else // the root's own box is never tested (bvh.cpp:313)
         w.lane_engine(0u, active, sv.root_ref, 0.0f);
     w.flush_leaves(1u);

@@ -173,6 +173,7 @@ typedef struct rt_counters {
     uint64_t tri_fetches;    /* wave-level triangle fetches */
     uint64_t hits_shaded;    /* closest hits whose attributes were resolved and shaded */
     uint64_t rays_queued;    /* reflection rays written to a device queue */
+    uint64_t group_tests;    /* conservative ray / triangle-group box tests of the leaf phase (pruned policy only) */
 } rt_counters;
 
 typedef struct rt_scene rt_scene; /* opaque */

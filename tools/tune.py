@@ -56,4 +56,4 @@ for rnd in range(ROUNDS):
         res[v].append((time.perf_counter() - t0) / FRAMES * 1e3)
 for v in values:
     c = cnts[v]
-    print(f"{name}={v!s:>28}  ms/frame median {np.median(res[v]):.3f} min {min(res[v]):.3f}  box {c['box_tests']/1e6:.1f}M tri {c['tri_tests']/1e6:.1f}M rays {c['rays']}  rounds " + " ".join(f"{x:.3f}" for x in res[v]))
+    print(f"{name}={v!s:>28}  ms/frame median {np.median(res[v]):.3f} min {min(res[v]):.3f}  box {c['box_tests']/1e6:.1f}M grp {c.get('group_tests',0)/1e6:.1f}M tri {c['tri_tests']/1e6:.1f}M rays {c['rays']}  rounds " + " ".join(f"{x:.3f}" for x in res[v]))
