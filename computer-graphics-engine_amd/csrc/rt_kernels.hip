@@ -221,7 +221,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         }
     } tl_end { a.sv.stamps, tl_begin, wave, lane, nullptr };
 #endif
+#ifdef RT_SHARE // tail work sharing ("Helpers" below): measured neutral to negative, compiled out by default
     uint32_t* const sched = a.share.sched;
+#else
+    uint32_t* const sched = nullptr;
+#endif
     if (sched && lane == 0)
         sh_add(&sched[SH_STARTED0 + (wave & 63u) * SH_SLOT_STRIDE], 1u);
     if (!sched && ballot(active) == 0)
