@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 };
+std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 }, g_fused_from { 0 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -334,7 +334,10 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.depth = n_levels - 1;
     a.parallelogram_n = p.parallelogram_n, a.segment_n = p.segment_n, a.seed = p.seed;
     a.min_waves = (uint32_t)g_min_waves.load();
-    a.fused = g_fused.load() ? 1u : 0u;
+    const bool fused = g_fused.load() != 0;
+    // fused_from = k: levels below k get a launch each (rays re-packed through the device
+    // queue between them), level k's launch then runs all deeper levels inside its waves
+    const int32_t fused_from = fused ? std::min(g_fused_from.load(), n_levels - 1) : n_levels;
     a.prio_levels = g_prio.load() ? 1u : 0u;
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
@@ -346,8 +349,9 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.state = sc.state.p;
     a.n_items = n_items;
     a.counters = counters_dev;
-    for (int32_t level = 0; level < (a.fused ? 1 : n_levels); level++) {
+    for (int32_t level = 0; level <= std::min(fused_from, n_levels - 1); level++) {
         a.level = level;
+        a.fused = level == fused_from ? 1u : 0u;
         a.direct = sc.direct.p + (size_t)level * n_items * 3;
         if (level == 0) {
             a.source = source;
@@ -471,6 +475,12 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "prio") == 0) { // 1: deeper recursion levels get a higher wave priority (default)
         g_prio.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "fused_from") == 0) { // first recursion level that runs fused (0 = one launch per frame)
+        if (value < 0 || value > 64)
+            return fail(RT_ERR_INVALID, "rt_set_option: fused_from out of range");
+        g_fused_from.store(value);
         return RT_OK;
     }
     if (name && strcmp(name, "share") == 0) { // 1: tail work sharing between the waves of a fused launch (default)

@@ -2,7 +2,12 @@
 """Copy the judged summaries of gpurun_out/round_profile/ into profiles/ (tracked):
 rocprofv3 kernel stats, per-level launch durations, PMC table, and hbm_traffic.json
 (bench.py reads it for roofline.traffic). Usage: tools/collect_profiles.py r01"""
-import csv, glob, json, shutil, sys, collections
+import csv, glob, json, os, shutil, sys, collections
+
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: take the latest of each kind"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 from pathlib import Path
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 R = Path(__file__).resolve().parent.parent
@@ -10,17 +15,17 @@ src = R / "gpurun_out" / "round_profile"
 dst = R / "profiles"
 dst.mkdir(exist_ok=True)
 shutil.copy(src / "bench_default.json", dst / f"{tag}_bench_default.json")
-ks = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))[0]
+ks = newest(str(src / "stats" / "*" / "*_kernel_stats.csv"))
 shutil.copy(ks, dst / f"{tag}_rocprofv3_kernel_stats.csv")
 # per-level launch durations from the kernel trace (last 20 frames)
-rows = list(csv.DictReader(open(glob.glob(str(src / "stats" / "*" / "*_kernel_trace.csv"))[0])))
+rows = list(csv.DictReader(open(newest(str(src / "stats" / "*" / "*_kernel_trace.csv")))))
 tr = [r for r in rows if "k_trace_level<false>" in r["Kernel_Name"]]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
 bench = json.loads(open(src / "bench_default.json").read().strip().splitlines()[-1])
 LPF = max(1, int(round(bench["roofline"]["launches_per_frame"])))  # k_trace_level launches per frame (1 = fused)
 levels = [dur[i::LPF][-20:] for i in range(LPF)] if len(dur) % LPF == 0 else []
 pm = {}
-for f in sorted(glob.glob(str(src / "pmc" / "*" / "*" / "*_counter_collection.csv"))):
+for f in sorted(newest(str(pd / "*" / "*_counter_collection.csv")) for pd in (src / "pmc").iterdir() if pd.is_dir()):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
         if "k_trace_level<false>" in r["Kernel_Name"]:
