@@ -188,8 +188,13 @@ int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len);
 
 /* Process-wide options. "unpruned" = 1: traverse with the reference's own policy
  * (every leaf whose boxes are hit is tested, src/bounding_volume_hierarchy.cpp:334-355);
- * 0 (default): additionally skip subtrees that provably cannot hold the closest
- * candidate (csrc/rt_device.h "Pruning") — results are identical bit for bit. */
+ * 0 (default): additionally skip subtrees and leaf triangle groups that provably
+ * cannot hold the closest candidate (csrc/rt_device.h "Pruning", csrc/rt_layout.h
+ * GroupRecord) — results are identical bit for bit.
+ * Scheduling / tuning options, none of which changes any result: "fused" (1: all
+ * recursion levels in one launch), "fused_from", "tile_wlog" / "tile_hlog" (primary
+ * tile = 2^w x 2^h pixels per wave), "tile_order" (1: centre-first dispatch),
+ * "leaf_flush", "min_waves", "super_log". Unknown names return RT_ERR_INVALID. */
 int rt_set_option(const char* name, int value);
 
 /* Select the HIP device used by subsequent creates on this thread. */
