@@ -26,7 +26,7 @@ EXPORTS = [
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips",
     "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
-    "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp",
+    "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp", "rt_bloom_device",
 ]
 
 
@@ -123,6 +123,7 @@ class Library:
         for n in ("rt_bvh_num_levels", "rt_bvh_num_leaves", "rt_bvh_num_nodes", "rt_bvh_num_prims"):
             getattr(c, n).argtypes = [C.c_void_p]
         c.rt_bvh_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        c.rt_bloom_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(abi.RenderParams), C.c_void_p]
         c.rt_camera_from_trackball.argtypes = [C.c_float, C.c_float, C.c_float * 3, C.c_float, C.c_float * 3,
                                                C.POINTER(abi.Camera)]
         c.rt_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Features),
@@ -231,6 +232,11 @@ class Library:
         self._check(self.c.rt_camera_from_trackball(fovy, aspect, _f3(look_at), distance, _f3(rotation),
                                                     C.byref(cam)))
         return cam
+
+    def bloom_device(self, rgb_ptr: int, width: int, height: int, params, stream: int = 0):
+        """≙ renderBloomFilter on a whole row-flipped frame in device memory."""
+        self._check(self.c.rt_bloom_device(C.c_void_p(rgb_ptr), width, height, C.byref(params),
+                                           C.c_void_p(stream) if stream else None))
 
     # -- ≙ renderRayTracing (host framebuffer)
     def render(self, bvh: Bvh, cam, features, params, width, height, rows=None, count=False):

@@ -89,6 +89,8 @@ struct Scratch {
     DevBuf<int32_t> rows;
     std::vector<int32_t> rows_host;
     DevBuf<uint32_t> order; // tile dispatch order (tile_order_for)
+    DevBuf<float> samples;   // per-sample colours of multi-sample frames (k_resolve input)
+    DevBuf<float> bloom_src; // the frame before the bloom filter
     // tail work sharing of fused launches (rt_kernels.h ShareArgs)
     DevBuf<uint32_t> share_sched;
     DevBuf<unsigned long long> share_queue;
@@ -209,12 +211,6 @@ int check_features(const rt_features* f, const rt_bvh* bvh)
 {
     if (!f)
         return fail(RT_ERR_INVALID, "features == NULL");
-    if (f->enableBloomEffect)
-        return fail(RT_ERR_UNSUPPORTED, "enableBloomEffect (render.cpp:158-210) is outside the hot-path scope");
-    if (f->enableMultipleRaysPerPixel)
-        return fail(RT_ERR_UNSUPPORTED, "enableMultipleRaysPerPixel (render.cpp:295-303) is outside the hot-path scope");
-    if (f->enableDepthOfField)
-        return fail(RT_ERR_UNSUPPORTED, "enableDepthOfField (render.cpp:305-314) is outside the hot-path scope");
     if (f->enableGlossyReflection)
         return fail(RT_ERR_UNSUPPORTED, "enableGlossyReflection (render.cpp:56-99) is outside the hot-path scope");
     if (f->enableTransparency)
@@ -230,8 +226,8 @@ int check_params(const rt_render_params* p)
 {
     if (!p)
         return fail(RT_ERR_INVALID, "params == NULL");
-    if (p->depth < 0 || p->depth > 62)
-        return fail(RT_ERR_INVALID, "depth must be in [0, 62]");
+    if (p->depth < 0 || p->depth > 61) // RNG streams 62 / 63 belong to the pixel samples
+        return fail(RT_ERR_INVALID, "depth must be in [0, 61]");
     if (p->parallelogram_n < 0 || p->parallelogram_n > 181 || p->segment_n < 0 || p->segment_n > 32767)
         return fail(RT_ERR_INVALID, "light sample counts out of range");
     return RT_OK;
@@ -264,7 +260,22 @@ rt::CameraArgs camera_args(const rt_camera& c, int32_t w, int32_t h)
     a.tile_wlog = (uint32_t)g_tile_wlog.load(), a.tile_hlog = (uint32_t)g_tile_hlog.load();
     a.super_log = (uint32_t)g_super_log.load();
     a.order = nullptr;
+    a.vwidth = w, a.spp = 1, a.ms_n = 0, a.dof_n = 0;
+    memcpy(a.look_at, c.look_at, 12);
+    a.focus = 0.0f, a.blur = 0.0f, a.seed = 0u;
     return a;
+}
+
+// the pixel loop's samples (render.cpp:295-314): n x n jittered rays and / or samplesDoF lens rays
+void camera_samples(rt::CameraArgs& a, const rt_features& f, const rt_render_params& p)
+{
+    a.ms_n = f.enableMultipleRaysPerPixel ? p.rays_per_pixel_side : 0;
+    a.dof_n = f.enableDepthOfField ? p.samples_dof : 0;
+    a.spp = a.ms_n * a.ms_n + a.dof_n;
+    if (a.spp == 0)
+        a.spp = 1;
+    a.vwidth = a.width * a.spp;
+    a.focus = p.focus_plane_distance, a.blur = p.blur_strength, a.seed = p.seed;
 }
 
 // Dispatch order of the primary tiles: nearest to the image centre first. Workgroups start
@@ -277,8 +288,8 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
     if (!g_tile_order.load() || cam.super_log != 0)
         return RT_OK;
     const int64_t tw = 1 << cam.tile_wlog, th = 1 << cam.tile_hlog;
-    const int64_t tiles_x = (cam.width + tw - 1) / tw, tiles_y = (cam.n_rows + th - 1) / th;
-    std::vector<int64_t> key { cam.width, cam.height, cam.n_rows, cam.row0, tw, th, cam.rows ? 1 : 0 };
+    const int64_t tiles_x = (cam.vwidth + tw - 1) / tw, tiles_y = (cam.n_rows + th - 1) / th;
+    std::vector<int64_t> key { cam.vwidth, cam.height, cam.n_rows, cam.row0, tw, th, cam.rows ? 1 : 0 };
     if (cam.rows)
         key.insert(key.end(), sc.rows_host.begin(), sc.rows_host.end());
     if (key != sc.order_key || !sc.order.p) {
@@ -289,7 +300,7 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
             const int64_t y = cam.rows ? sc.rows_host[(size_t)lrow] : cam.row0 + lrow;
             for (int64_t tx = 0; tx < tiles_x; tx++) {
                 const int64_t x = tx * tw + tw / 2;
-                const int64_t dx = 2 * x - cam.width, dy = 2 * y - cam.height;
+                const int64_t dx = 2 * x - cam.vwidth, dy = 2 * y - cam.height;
                 d[(size_t)(ty * tiles_x + tx)] = { dx * dx + dy * dy, (uint32_t)(ty * tiles_x + tx) };
             }
         }
@@ -659,7 +670,106 @@ int rt_camera_from_trackball(float fovy, float aspect, const float look_at[3], f
     const float uuv[3] = { y * uv[2] - uv[1] * z, z * uv[0] - uv[2] * x, x * uv[1] - uv[0] * y };
     for (int k = 0; k < 3; k++)
         out->origin[k] = look_at[k] + (v[k] + ((uv[k] * w) + uuv[k]) * 2.0f);
+    memcpy(out->look_at, look_at, 12);
     return RT_OK;
+}
+
+namespace {
+
+// weightsGaussian(sigma), src/render.cpp:198-210 (answer[i + 1][k + 1], then / sum). The
+// reference's unqualified exp() on a float argument is ::exp(double) with <cmath> alone.
+void weights_gaussian(float sigma, float out[3][3])
+{
+    float sum = 0.0f;
+    for (int i = -1; i < 2; i++) {
+        for (int k = -1; k < 2; k++) {
+            const float weight = (float)(::exp((double)(-(i * i + k * k) / (2 * sigma * sigma))) / (2 * 3.1415 * sigma * sigma));
+            out[i + 1][k + 1] = weight;
+            sum += weight;
+        }
+    }
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++)
+            out[i][k] = out[i][k] / sum;
+}
+
+// renderBloomFilter on a whole row-flipped frame in device memory
+int enqueue_bloom(Scratch& sc, float* frame_dev, int32_t width, int32_t height, const rt_render_params& p,
+    hipStream_t stream)
+{
+    const size_t floats = (size_t)width * height * 3;
+    HIP_TRY(sc.bloom_src.reserve(floats));
+    HIP_TRY(hipMemcpyAsync(sc.bloom_src.p, frame_dev, floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    rt::BloomArgs b;
+    b.src = sc.bloom_src.p, b.frame = frame_dev, b.width = width, b.height = height;
+    weights_gaussian(1.0f, b.w);
+    b.scalar = p.bloom_scalar, b.threshold = p.bloom_threshold, b.debug_option = p.bloom_debug_option;
+    rt::launch_bloom(b, stream);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// ≙ the pixel loop of renderRayTracing (render.cpp:283-324) for the rows described by `cam`
+// (+ renderBloomFilter when the whole frame is rendered). `fold` carries the output mapping.
+int enqueue_frame(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_render_params& p, rt::CameraArgs cam,
+    rt::FoldArgs fold, bool whole_frame, rt_counters* counters_dev, hipStream_t stream)
+{
+    if (f.enableMultipleRaysPerPixel && (p.rays_per_pixel_side < 1 || p.rays_per_pixel_side > 32))
+        return fail(RT_ERR_INVALID, "rays_per_pixel_side must be in [1, 32]");
+    if (f.enableDepthOfField && (p.samples_dof < 1 || p.samples_dof > 1024))
+        return fail(RT_ERR_INVALID, "samples_dof must be in [1, 1024]");
+    if (f.enableBloomEffect && !whole_frame)
+        return fail(RT_ERR_UNSUPPORTED,
+            "enableBloomEffect filters the WHOLE frame (render.cpp:326-328): render the rows without it and call "
+            "rt_bloom_device once the frame is assembled");
+    camera_samples(cam, f, p);
+    const uint64_t n_items64 = (uint64_t)cam.n_rows * (uint64_t)cam.vwidth;
+    if (n_items64 > (1ull << 30) || (uint64_t)cam.height * (uint64_t)cam.vwidth > 0xffffffffull)
+        return fail(RT_ERR_INVALID, "too many samples: rows x width x samples per pixel must be <= 2^30");
+    const uint32_t n_items = (uint32_t)n_items64;
+    int rc;
+    if (cam.spp == 1) {
+        rc = enqueue_trace(bvh, sc, f, p, rt::SRC_CAMERA, cam, rt::RaySoA {}, n_items, fold, counters_dev, stream);
+    } else {
+        HIP_TRY(sc.samples.reserve((size_t)n_items * 3));
+        rt::FoldArgs sf;
+        memset(&sf, 0, sizeof(sf));
+        sf.packed = 1, sf.out = sc.samples.p;
+        rc = enqueue_trace(bvh, sc, f, p, rt::SRC_CAMERA, cam, rt::RaySoA {}, n_items, sf, counters_dev, stream);
+        if (rc != RT_OK)
+            return rc;
+        rt::ResolveArgs r;
+        r.samples = sc.samples.p, r.n_pixels = (uint32_t)cam.n_rows * (uint32_t)cam.width;
+        r.spp = cam.spp, r.ms_n = cam.ms_n, r.dof_n = cam.dof_n;
+        r.width = fold.width, r.height = fold.height, r.row0 = fold.row0, r.packed = fold.packed, r.rows = fold.rows;
+        r.out = fold.out;
+        rt::launch_resolve(r, stream);
+        HIP_TRY(hipGetLastError());
+    }
+    if (rc == RT_OK && f.enableBloomEffect)
+        rc = enqueue_bloom(sc, fold.out, cam.width, cam.height, p, stream);
+    return rc;
+}
+
+} // namespace
+
+int rt_bloom_device(float* rgb_dev, int32_t width, int32_t height, const rt_render_params* params, void* hip_stream)
+{
+    if (!rgb_dev || !params)
+        return fail(RT_ERR_INVALID, "rt_bloom_device: null argument");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30)
+        return fail(RT_ERR_INVALID, "rt_bloom_device: bad resolution");
+    static std::mutex mu;
+    static std::map<void*, std::unique_ptr<Scratch>> scratch; // keyed by stream (no BVH handle involved)
+    Scratch* sc;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto& s = scratch[hip_stream];
+        if (!s)
+            s.reset(new Scratch);
+        sc = s.get();
+    }
+    return enqueue_bloom(*sc, rgb_dev, width, height, *params, (hipStream_t)hip_stream);
 }
 
 int rt_render_device(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features,
@@ -701,9 +811,7 @@ int rt_render_device(const rt_bvh* cbvh, const rt_camera* camera, const rt_featu
     memset(&fold, 0, sizeof(fold));
     fold.width = width, fold.height = height, fold.row0 = cam.row0, fold.packed = packed, fold.rows = cam.rows;
     fold.out = rgb_dev;
-    const uint32_t n_items = (uint32_t)cam.n_rows * (uint32_t)width;
-    return enqueue_trace(bvh, sc, *features, *params, rt::SRC_CAMERA, cam, rt::RaySoA {}, n_items, fold,
-        counters_dev, stream);
+    return enqueue_frame(bvh, sc, *features, *params, cam, fold, rows == nullptr && !packed, counters_dev, stream);
 }
 
 int rt_render(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features,
@@ -734,8 +842,7 @@ int rt_render(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* fe
     memset(&fold, 0, sizeof(fold));
     fold.width = width, fold.height = height, fold.row0 = row_begin, fold.packed = 0, fold.rows = nullptr;
     fold.out = sc.frame.p;
-    const uint32_t n_items = (uint32_t)cam.n_rows * (uint32_t)width;
-    rc = enqueue_trace(bvh, sc, *features, *params, rt::SRC_CAMERA, cam, rt::RaySoA {}, n_items, fold,
+    rc = enqueue_frame(bvh, sc, *features, *params, cam, fold, row_begin == 0 && row_end == height,
         counters ? sc.counters.p : nullptr, nullptr);
     if (rc != RT_OK)
         return rc;

@@ -28,6 +28,11 @@ struct CameraArgs {
     uint32_t tile_wlog, tile_hlog; // primary tile = 2^wlog x 2^hlog pixels per wave (<= 64)
     uint32_t super_log;            // > 0: super-tiles of 2^s x 2^s tiles dealt to the XCDs (tile_pixel)
     const uint32_t* order;         // NULL, or launch position -> tile index (heavy-first dispatch order)
+    // samples per pixel (src/render.cpp:295-314): ms_n x ms_n jittered rays, then dof_n lens rays;
+    // the launch sees a VIRTUAL image of vwidth = width * spp columns, column x * spp + s = sample s of pixel x
+    int32_t vwidth, spp, ms_n, dof_n;
+    float look_at[3], focus, blur;
+    uint32_t seed;
 };
 
 // Tail work sharing of a fused launch (k_trace_level, "Helpers"). All words are zeroed by
@@ -83,6 +88,26 @@ struct FoldArgs {
     float* out;
 };
 
+// Per-pixel combination of the samples (renderRayTracing, src/render.cpp:295-322) — k_resolve
+struct ResolveArgs {
+    const float* samples; // n_pixels * spp colours, sample-major inside a pixel
+    uint32_t n_pixels;
+    int32_t spp, ms_n, dof_n;
+    int32_t width, height, row0, packed;
+    const int32_t* rows;
+    float* out;
+};
+
+// renderBloomFilter (src/render.cpp:157-196) — k_bloom
+struct BloomArgs {
+    const float* src; // copy of the frame before the filter
+    float* frame;
+    int32_t width, height;
+    float w[3][3];    // weightsGaussian(1.0f), computed on the host
+    float scalar, threshold;
+    int32_t debug_option;
+};
+
 struct IntersectArgs {
     SceneView sv;
     uint32_t flags;
@@ -105,6 +130,8 @@ void set_diag_leaf(const float4* p);
 uint32_t trace_level_groups(const LevelArgs& a); // workgroups launch_trace_level will start
 void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s);
 void launch_fold(const FoldArgs& a, hipStream_t s);
+void launch_resolve(const ResolveArgs& a, hipStream_t s);
+void launch_bloom(const BloomArgs& a, hipStream_t s);
 void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s);
 void launch_div_check(uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t per_thread, unsigned long long* out,
     hipStream_t s);

@@ -45,16 +45,57 @@ RT_DEV V3 quat_rotate(const float* q, V3 v)
     return v + ((uv * q[0]) + uuv) * 2.0f;
 }
 
-// Trackball::generateRay (trackball.cpp:101-110) for pixel (x, y) of a W x H frame
-RT_DEV RayL camera_ray(const CameraArgs& c, int32_t x, int32_t y)
+// Trackball::generateRay (trackball.cpp:101-110) for the normalised position (px, py)
+RT_DEV RayL generate_ray(const CameraArgs& c, float px, float py)
 {
-    const float px = float(x) / float(c.width) * 2.0f - 1.0f; // render.cpp:286-289
-    const float py = float(y) / float(c.height) * 2.0f - 1.0f;
     const V3 csd = normalize(mk(-px * c.half_w, py * c.half_h, 1.0f));
     RayL r;
     r.o = mk(c.origin[0], c.origin[1], c.origin[2]);
     r.d = quat_rotate(c.quat, csd);
     return r;
+}
+
+// Primary ray of virtual column xv (= pixel xv / spp, sample xv % spp) of row y.
+// Plain path: render.cpp:286-289,317. Samples: getRaySamples (:211-229) and getDOFRays
+// (:245-276) with the counter-based generator in place of std::mt19937 (streams 62 / 63,
+// keyed by pixel and sample — the oracle draws the same numbers).
+RT_DEV RayL camera_ray(const CameraArgs& c, int32_t xv, int32_t y)
+{
+    const int32_t x = c.spp == 1 ? xv : xv / c.spp;
+    const float px = float(x) / float(c.width) * 2.0f - 1.0f;
+    const float py = float(y) / float(c.height) * 2.0f - 1.0f;
+    if (c.spp == 1 && c.ms_n == 0 && c.dof_n == 0)
+        return generate_ray(c, px, py);
+    const int32_t s = xv - x * c.spp;
+    const uint32_t pixel = (uint32_t)y * (uint32_t)c.width + (uint32_t)x;
+    const int32_t n = c.ms_n;
+    if (s < n * n) {
+        const float pixelBoxX = (1 / float(c.width) * 2.f) / float(n), pixelBoxY = (1 / float(c.height) * 2.f) / float(n);
+        const int32_t i = s / n, j = s - i * n;
+        const float newPosX = px + float(i) * pixelBoxX, newPosY = py + float(j) * pixelBoxY;
+        const float jx = rand01(rand31(c.seed, pixel, 62u, 0u, (uint32_t)s, 0u)) * pixelBoxX;
+        const float jy = rand01(rand31(c.seed, pixel, 62u, 0u, (uint32_t)s, 1u)) * pixelBoxY;
+        return generate_ray(c, newPosX + jx, newPosY + jy);
+    }
+    const uint32_t k = (uint32_t)(s - n * n);
+    // getPlane (:231-236): normal = normalize(lookAt - position), D = dist - sqrt(dot(position, position))
+    const V3 position = mk(c.origin[0], c.origin[1], c.origin[2]);
+    const V3 N = normalize(mk(c.look_at[0], c.look_at[1], c.look_at[2]) - position);
+    const float focalD = c.focus - sqrtf(dot(position, position));
+    const RayL ray = generate_ray(c, px, py);
+    V3 v1 = normalize(mk(-N.y, N.x, 0.0f));
+    if (N.x == 0.f && N.y == 0.f)
+        v1 = normalize(mk(N.z, 0.0f, -N.x));
+    const V3 v2 = normalize(cross(N, v1));
+    const float tf = (focalD - dot(N, ray.o)) / dot(N, ray.d); // getIntersection (:238-243)
+    const V3 focalPoint = ray.o + tf * ray.d;
+    const float r = sqrtf(rand01(rand31(c.seed, pixel, 63u, 0u, k, 0u)) * c.blur);
+    const float theta = rand01(rand31(c.seed, pixel, 63u, 0u, k, 1u)) * (3.14159265358979323846264338327950288f * 2);
+    const float ct = (float)cos((double)theta), st = (float)sin((double)theta); // as the oracle: via double
+    RayL out;
+    out.o = ray.o + r * ct * v1 + r * st * v2;
+    out.d = focalPoint - out.o;
+    return out;
 }
 
 // lane → pixel of the wave's tile (2^tile_wlog x 2^tile_hlog pixels; lanes past the
@@ -69,7 +110,7 @@ RT_DEV RayL camera_ray(const CameraArgs& c, int32_t x, int32_t y)
 RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_t& x, int32_t& y, int32_t& lrow)
 {
     const uint32_t tw = 1u << c.tile_wlog, th = 1u << c.tile_hlog;
-    const uint32_t tiles_x = ((uint32_t)c.width + tw - 1u) >> c.tile_wlog;
+    const uint32_t tiles_x = ((uint32_t)c.vwidth + tw - 1u) >> c.tile_wlog;
     uint32_t tx, ty;
     if (c.super_log == 0) {
         if (c.order)
@@ -88,7 +129,7 @@ RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_
     }
     x = (int32_t)(tx * tw + (lane & (tw - 1u)));
     lrow = (int32_t)(ty * th + (lane >> c.tile_wlog));
-    const bool ok = lane < tw * th && tx < tiles_x && x < c.width && lrow < c.n_rows;
+    const bool ok = lane < tw * th && tx < tiles_x && x < c.vwidth && lrow < c.n_rows;
     y = 0;
     if (ok)
         y = c.rows ? c.rows[lrow] : c.row0 + lrow;
@@ -168,8 +209,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         active = tile_pixel(a.cam, wave, lane, x, y, lrow);
         if (active) {
             ray = camera_ray(a.cam, x, y);
-            item = (uint32_t)lrow * (uint32_t)a.cam.width + (uint32_t)x;
-            pixel = (uint32_t)y * (uint32_t)a.cam.width + (uint32_t)x;
+            item = (uint32_t)lrow * (uint32_t)a.cam.vwidth + (uint32_t)x; // x: virtual column (pixel * spp + sample)
+            pixel = (uint32_t)y * (uint32_t)a.cam.vwidth + (uint32_t)x;  // RNG key of the light samples
         }
     } else {
         const uint32_t count = a.source == SRC_QUEUE ? *a.in_count : a.in_count_imm;
@@ -561,6 +602,76 @@ __global__ __launch_bounds__(256) void k_fold(const FoldArgs a)
     p[0] = finalColor.x, p[1] = finalColor.y, p[2] = finalColor.z;
 }
 
+// renderRayTracing's per-pixel combination of its samples (src/render.cpp:292-322)
+__global__ __launch_bounds__(256) void k_resolve(const ResolveArgs a)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= a.n_pixels)
+        return;
+    const float* sm = a.samples + 3 * (size_t)p * (size_t)a.spp;
+    V3 colorSum = mk(0.f, 0.f, 0.f);
+    uint32_t weight = 0;
+    int32_t s = 0;
+    if (a.ms_n > 0) {
+        V3 color = mk(0.f, 0.f, 0.f);
+        for (int32_t i = 0; i < a.ms_n * a.ms_n; i++, s++)
+            color = color + ld3(sm + 3 * s);
+        color = color / float(a.ms_n * a.ms_n);
+        colorSum = colorSum + color;
+        weight++;
+    }
+    if (a.dof_n > 0) {
+        V3 color = mk(0.f, 0.f, 0.f);
+        for (int32_t i = 0; i < a.dof_n; i++, s++)
+            color = color + ld3(sm + 3 * s);
+        color = color / float(a.dof_n);
+        colorSum = colorSum + color * 3.f;
+        weight += 3;
+    }
+    if (a.ms_n == 0 && a.dof_n == 0) {
+        colorSum = colorSum + ld3(sm);
+        weight++;
+    }
+    const V3 finalColor = colorSum / float(weight);
+    size_t o = p;
+    if (!a.packed) {
+        const int32_t lrow = (int32_t)(p / (uint32_t)a.width);
+        const int32_t x = (int32_t)(p - (uint32_t)lrow * (uint32_t)a.width);
+        const int32_t y = a.rows ? a.rows[lrow] : a.row0 + lrow;
+        o = (size_t)(a.height - 1 - y) * a.width + x; // Screen::setPixel, screen.cpp:45
+    }
+    a.out[3 * o] = finalColor.x, a.out[3 * o + 1] = finalColor.y, a.out[3 * o + 2] = finalColor.z;
+}
+
+// renderBloomFilter (src/render.cpp:157-196): one thread per pixel (x, y), x < W - 1, y < H - 1
+__global__ __launch_bounds__(256) void k_bloom(const BloomArgs a)
+{
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    const int32_t W = a.width, H = a.height;
+    if (id >= (uint32_t)(W - 1) * (uint32_t)(H - 1))
+        return;
+    const int32_t y = (int32_t)(id / (uint32_t)(W - 1)), x = (int32_t)(id - (uint32_t)y * (uint32_t)(W - 1));
+    const size_t idx = (size_t)(H - 1 - y) * W + x; // Screen::indexAt
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    for (int k = -1; k < 2; k++) {
+        for (int j = -1; j < 2; j++) {
+            if (!(x + k < 0 || x + k > W - 1 || y + j < 0 || y + j > H - 1)) {
+                const size_t ti = (size_t)(H - 1 - (y + j)) * W + (x + k);
+                V3 c = ld3(a.src + 3 * ti);
+                // threshold pass (:165-170): brightness in double, kept as float
+                const float brightness = (float)(0.2126 * (double)c.x + 0.7152 * (double)c.y + 0.0722 * (double)c.z);
+                if (brightness < a.threshold)
+                    c = mk(0.0f, 0.0f, 0.0f);
+                sum = sum + c * a.w[k + 1][j + 1];
+            }
+        }
+    }
+    const V3 orig = ld3(a.src + 3 * idx);
+    const V3 newColor = orig + sum * a.scalar;
+    const V3 outc = a.debug_option == 0 ? newColor : (a.debug_option == 1 ? sum * a.scalar : orig);
+    a.frame[3 * idx] = outc.x, a.frame[3 * idx + 1] = outc.y, a.frame[3 * idx + 2] = outc.z;
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect(const IntersectArgs a)
 {
@@ -706,7 +817,7 @@ uint32_t grid_for_waves(uint64_t waves) { return (uint32_t)((waves + (kBlock / 6
 uint64_t camera_waves(const CameraArgs& c)
 {
     const uint32_t tw = 1u << c.tile_wlog, th = 1u << c.tile_hlog;
-    const uint64_t tiles_x = (c.width + tw - 1) / tw, tiles_y = (c.n_rows + th - 1) / th;
+    const uint64_t tiles_x = (c.vwidth + tw - 1) / tw, tiles_y = (c.n_rows + th - 1) / th;
     if (c.super_log == 0)
         return tiles_x * tiles_y;
     const uint32_t s = c.super_log;
@@ -756,6 +867,20 @@ void launch_fold(const FoldArgs& a, hipStream_t s)
     if (a.n_items == 0)
         return;
     hipLaunchKernelGGL(k_fold, dim3((a.n_items + 255) / 256), dim3(256), 0, s, a);
+}
+
+void launch_resolve(const ResolveArgs& a, hipStream_t s)
+{
+    if (a.n_pixels)
+        hipLaunchKernelGGL(k_resolve, dim3((a.n_pixels + 255) / 256), dim3(256), 0, s, a);
+}
+
+void launch_bloom(const BloomArgs& a, hipStream_t s)
+{
+    if (a.width > 1 && a.height > 1) {
+        const uint32_t n = (uint32_t)(a.width - 1) * (uint32_t)(a.height - 1);
+        hipLaunchKernelGGL(k_bloom, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    }
 }
 
 void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s)

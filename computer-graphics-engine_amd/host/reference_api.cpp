@@ -12,6 +12,13 @@
 int segmentLightSamples = 25;              // src/light.cpp:12
 int parallelogramLightDirectionSamples = 5; // src/light.cpp:13
 unsigned int areaLightSeed = 0;
+int raysPerPixelSide = 3;         // src/render.cpp:14
+int samplesDoF = 5;               // :15
+float focusPlaneDistance = 3.f;   // :16
+float blurStrength = .005f;       // :17
+float bloomScalar = .3f;          // :19
+float bloomThreshold = .4f;       // :20
+int bloomDebugOption = 0;         // :21
 
 namespace {
 
@@ -59,6 +66,14 @@ rt_render_params params_for(int depth)
     p.parallelogram_n = parallelogramLightDirectionSamples;
     p.segment_n = segmentLightSamples;
     p.seed = areaLightSeed;
+    // the extras' globals of src/render.cpp:14-22
+    p.rays_per_pixel_side = raysPerPixelSide;
+    p.samples_dof = samplesDoF;
+    p.focus_plane_distance = focusPlaneDistance;
+    p.blur_strength = blurStrength;
+    p.bloom_scalar = bloomScalar;
+    p.bloom_threshold = bloomThreshold;
+    p.bloom_debug_option = bloomDebugOption;
     return p;
 }
 

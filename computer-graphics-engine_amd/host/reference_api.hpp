@@ -203,6 +203,14 @@ extern int segmentLightSamples;
 extern int parallelogramLightDirectionSamples;
 // area-light RNG seed (the reference uses the process-global rand())
 extern unsigned int areaLightSeed;
+// src/render.h:11-16,25-28 — the extras' sliders, read at render time
+extern float bloomScalar;
+extern float bloomThreshold;
+extern int bloomDebugOption;
+extern int raysPerPixelSide;
+extern int samplesDoF;
+extern float focusPlaneDistance;
+extern float blurStrength;
 
 // src/render.h:32,35
 void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features);

@@ -78,6 +78,13 @@ class StripRenderer:
         self.counters = torch.zeros(16, dtype=torch.int64, device="cuda")
         self.overlap = overlap and world > 1
         self.k = 0
+        # renderBloomFilter works on the WHOLE frame (render.cpp:326-328): with several ranks the
+        # strips are rendered without it and every rank filters its assembled copy of the frame
+        self.bloom = bool(features.enableBloomEffect) and world > 1
+        self.f_strips = features
+        if self.bloom:
+            self.f_strips = type(features).from_buffer_copy(bytes(features))
+            self.f_strips.enableBloomEffect = 0
         if world > 1:
             rmax = rows_max(height, strip_rows, world)
             nbuf = 2 if self.overlap else 1
@@ -104,12 +111,14 @@ class StripRenderer:
         cur = torch.cuda.current_stream()
         if self.overlap and self.used[i]:
             cur.wait_event(self.consumed[i])  # the exchange two frames ago must have read this buffer
-        self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local[i].data_ptr(),
+        self.rt.render_device(self.bvh, self.cam, self.f_strips, self.p, self.W, self.H, self.local[i].data_ptr(),
                               rows=self.rows, packed=True, stream=stream)
         if not self.overlap:
             gather_strips(self.gathered[i], self.local[i])
             self.rt.deinterleave_strips(self.gathered[i].data_ptr(), self.frame.data_ptr(), self.W, self.H,
                                         self.strip_rows, self.world, stream=stream)
+            if self.bloom:
+                self.rt.bloom_device(self.frame.data_ptr(), self.W, self.H, self.p, stream=stream)
             return
         self.rendered[i].record(cur)
         with torch.cuda.stream(self.comm_stream):
@@ -117,6 +126,8 @@ class StripRenderer:
             gather_strips(self.gathered[i], self.local[i])
             self.rt.deinterleave_strips(self.gathered[i].data_ptr(), self.frame.data_ptr(), self.W, self.H,
                                         self.strip_rows, self.world, stream=self.comm_stream.cuda_stream)
+            if self.bloom:
+                self.rt.bloom_device(self.frame.data_ptr(), self.W, self.H, self.p, stream=self.comm_stream.cuda_stream)
             self.consumed[i].record(self.comm_stream)
         self.used[i] = True
 
@@ -135,7 +146,7 @@ class StripRenderer:
             self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
                                   counters_ptr=self.counters.data_ptr(), stream=stream)
         else:
-            self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.local[0].data_ptr(),
+            self.rt.render_device(self.bvh, self.cam, self.f_strips, self.p, self.W, self.H, self.local[0].data_ptr(),
                                   rows=self.rows, packed=True, counters_ptr=self.counters.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         vals = self.counters.cpu().numpy().view(np.uint64)

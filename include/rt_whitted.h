@@ -135,6 +135,7 @@ typedef struct rt_camera {
     float quat[4];   /* glm::quat(eulerAngles) as (w,x,y,z) */
     float half_w;    /* m_halfScreenSpaceWidth  = aspect * tan(fovy/2) */
     float half_h;    /* m_halfScreenSpaceHeight = tan(fovy/2) */
+    float look_at[3]; /* Trackball::lookAt() — depth of field only (getPlane, src/render.cpp:225-230) */
 } rt_camera;
 
 /* ---- per-ray hit record, ≙ the observable result of
@@ -157,6 +158,14 @@ typedef struct rt_render_params {
     int32_t parallelogram_n;  /* samples per side (reference default 5) */
     int32_t segment_n;        /* samples (reference default 25) */
     uint32_t seed;            /* counter-based RNG seed */
+    /* the extras' globals (src/render.cpp:14-22); read only when their feature flag is set */
+    int32_t rays_per_pixel_side;  /* raysPerPixelSide (3): enableMultipleRaysPerPixel traces n x n jittered rays */
+    int32_t samples_dof;          /* samplesDoF (5): enableDepthOfField */
+    float focus_plane_distance;   /* focusPlaneDistance (3.f) */
+    float blur_strength;          /* blurStrength (.005f): sampling radius on the lens plane */
+    float bloom_scalar;           /* bloomScalar (.3f): enableBloomEffect */
+    float bloom_threshold;        /* bloomThreshold (.4f) */
+    int32_t bloom_debug_option;   /* bloomDebugOption (0 = final image, 1 = bloom only, else unfiltered) */
 } rt_render_params;
 
 /* ---- ray / test counters of one call (what SURVEY.md §8(d) prices) ------- */
@@ -228,6 +237,15 @@ int rt_bvh_export(const rt_bvh* bvh, float* node_aabb, int32_t* node_meta, int32
  *    (framework/src/trackball.cpp:23-31,64-74). Angles in radians. ---------- */
 int rt_camera_from_trackball(float fovy, float aspect, const float look_at[3], float distance,
                              const float rotation_euler[3], rt_camera* out);
+
+/* -- Bloom ≙ renderBloomFilter (src/render.cpp:157-196) on a complete W x H frame in device
+ *    memory (row-flipped, as rt_render_device writes it). rt_render applies it itself when
+ *    features.extra.enableBloomEffect is set; callers that assemble a frame from strips
+ *    (rt_render_device with a row list, multi-GPU) call it after the frame is whole.
+ *    The random samples of enableMultipleRaysPerPixel / enableDepthOfField (std::mt19937 seeded
+ *    from std::random_device in the reference, src/render.cpp:213-216,246-249) come from the
+ *    counter-based generator rt_rand31 keyed by (seed, pixel, sample). ---------------------- */
+int rt_bloom_device(float* rgb_dev, int32_t width, int32_t height, const rt_render_params* params, void* hip_stream);
 
 /* -- Frame ≙ renderRayTracing (src/render.cpp:273-329, plain path :316-323)
  *    with explicit depth. Renders image rows [row_begin,row_end) of a W x H

@@ -107,6 +107,7 @@ class Oracle:
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Features),
                                  C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.POINTER(abi.Counters), C.c_int]
+        L.orc_bloom.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(abi.RenderParams)]
         L.orc_rand31.restype = C.c_uint32
         L.orc_rand31.argtypes = [C.c_uint32] * 6
         L.orc_acquire_texel.argtypes = [C.c_void_p, C.c_int, C.c_float * 2, C.POINTER(abi.Features), C.c_float * 3]
@@ -160,7 +161,15 @@ class Oracle:
         self.lib.orc_render(bvh.handle, C.byref(cam), C.byref(features), C.byref(params), width, height, y0, y1,
                             rgb.ctypes.data if want_rgb else None, tb.ctypes.data if want_hits else None,
                             pr.ctypes.data if want_hits else None, C.byref(c), threads)
+        if want_rgb and features.enableBloomEffect and rows is None:
+            self.bloom(rgb, params)  # renderRayTracing applies it after the pixel loop (src/render.cpp:326-328)
         return rgb, tb, pr, c
+
+    def bloom(self, rgb: np.ndarray, params):
+        """≙ renderBloomFilter on a full row-flipped H x W x 3 float32 frame, in place."""
+        assert rgb.dtype == np.float32 and rgb.flags.c_contiguous
+        self.lib.orc_bloom(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], C.byref(params))
+        return rgb
 
     def rand31(self, seed, pixel, level, light, sample, dim) -> int:
         return int(self.lib.orc_rand31(seed, pixel, level, light, sample, dim))

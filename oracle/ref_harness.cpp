@@ -260,6 +260,7 @@ void ref_glm_camera(float fovy, float aspect, const float look_at[3], float dist
     out->quat[0] = q.w, out->quat[1] = q.x, out->quat[2] = q.y, out->quat[3] = q.z;
     glm::vec3 p = g3(look_at) + glm::quat(euler) * glm::vec3(0, 0, -distance);
     memcpy(out->origin, &p, 12);
+    memcpy(out->look_at, look_at, 12);
 }
 void ref_glm_generate_ray(float half_w, float half_h, const float rot[3], const float origin[3], float px, float py, rt_ray* out)
 {

@@ -766,6 +766,95 @@ inline Ray generateRay(const rt_camera& cam, float px, float py)
     return ray;
 }
 
+// ---------------------------------------------------------------------------
+// The pixel loop's extras (src/render.cpp:211-271). The reference draws its samples from a
+// std::mt19937 seeded by std::random_device per call — irreproducible; both sides of the
+// parity test use the counter-based generator instead (streams 62 / 63 of rt_rand31, keyed by
+// pixel and sample): uniform_real_distribution<float>(0, b) becomes rand01 * b.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kStreamMultiSample = 62, kStreamDoF = 63;
+
+// getRaySamples, src/render.cpp:211-229
+std::vector<Ray> getRaySamples(const rt_camera& cam, const rt_render_params& p, uint32_t pixel, float pixelPosX,
+    float pixelPosY, float pixelSizeX, float pixelSizeY, int n)
+{
+    std::vector<Ray> res;
+    const float pixelBoxX = pixelSizeX / float(n), pixelBoxY = pixelSizeY / float(n);
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) {
+            const uint32_t s = (uint32_t)(i * n + j);
+            const float newPosX = pixelPosX + float(i) * pixelBoxX, newPosY = pixelPosY + float(j) * pixelBoxY;
+            const float jx = rand01(rand31(p.seed, pixel, kStreamMultiSample, 0, s, 0)) * pixelBoxX;
+            const float jy = rand01(rand31(p.seed, pixel, kStreamMultiSample, 0, s, 1)) * pixelBoxY;
+            res.emplace_back(generateRay(cam, newPosX + jx, newPosY + jy));
+        }
+    }
+    return res;
+}
+
+struct PlaneDN {
+    float D;
+    V3 normal;
+};
+// getPlane, src/render.cpp:231-236: position() = cam.origin, lookAt() = cam.look_at
+inline PlaneDN getPlane(const rt_camera& cam, float dist)
+{
+    const V3 position = v3(cam.origin);
+    const V3 planeNormal = normalize(v3(cam.look_at) - position);
+    return PlaneDN { dist - std::sqrt(dot(position, position)), planeNormal };
+}
+// getIntersection, src/render.cpp:238-243
+inline V3 getIntersection(const Ray& ray, const PlaneDN& plane)
+{
+    const float t = (plane.D - dot(plane.normal, ray.origin)) / dot(plane.normal, ray.direction);
+    return ray.origin + t * ray.direction;
+}
+// getDOFRays, src/render.cpp:245-276. cos / sin of theta: correctly rounded from double on
+// both sides of the parity test (glm::cos(float) = cosf differs between libms in the last bit).
+std::vector<Ray> getDOFRays(const rt_camera& cam, const rt_render_params& p, uint32_t pixel, float pixelPosX,
+    float pixelPosY, float focalLength, float samplingRadius, int n)
+{
+    const PlaneDN focalPlane = getPlane(cam, focalLength);
+    const PlaneDN cameraPlane = getPlane(cam, 0.f);
+    const Ray ray = generateRay(cam, pixelPosX, pixelPosY);
+    const V3 N = cameraPlane.normal;
+    V3 v1 = normalize(v3(-N.y, N.x, 0));
+    if (N.x == 0.f && N.y == 0.f)
+        v1 = normalize(v3(N.z, 0, -N.x));
+    const V3 v2 = normalize(cross(N, v1));
+    const V3 focalPoint = getIntersection(ray, focalPlane);
+    std::vector<Ray> res;
+    for (int i = 0; i < n; i++) {
+        const float r = std::sqrt(rand01(rand31(p.seed, pixel, kStreamDoF, 0, (uint32_t)i, 0)) * samplingRadius);
+        const float theta = rand01(rand31(p.seed, pixel, kStreamDoF, 0, (uint32_t)i, 1)) * (3.14159265358979323846264338327950288f * 2);
+        const float ct = (float)std::cos((double)theta), st = (float)std::sin((double)theta);
+        const V3 newOrigin = ray.origin + r * ct * v1 + r * st * v2;
+        Ray out;
+        out.origin = newOrigin;
+        out.direction = focalPoint - newOrigin;
+        out.t = FLT_MAX;
+        res.push_back(out);
+    }
+    return res;
+}
+
+// weightsGaussian, src/render.cpp:198-210 (column-major mat3: answer[i + 1][k + 1]). The unqualified
+// exp() of the reference takes a float argument; with <cmath> alone that is ::exp(double).
+inline void weightsGaussian(float sigma, float out[3][3])
+{
+    float sum = 0.0f;
+    for (int i = -1; i < 2; i++) {
+        for (int k = -1; k < 2; k++) {
+            float weight = (float)(::exp((double)(-(i * i + k * k) / (2 * sigma * sigma))) / (2 * 3.1415 * sigma * sigma));
+            out[i + 1][k + 1] = weight;
+            sum += weight;
+        }
+    }
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++)
+            out[i][k] = out[i][k] / sum;
+}
+
 void addCounters(rt_counters* out, const Counters& c)
 {
     if (!out)
@@ -905,6 +994,7 @@ void orc_camera_from_trackball(float fovy, float aspect, const float look_at[3],
     out->quat[3] = cx * cy * sz - sx * sy * cz;
     V3 p = v3(look_at) + quatRotate(out->quat, v3(0, 0, -distance));
     out->origin[0] = p.x, out->origin[1] = p.y, out->origin[2] = p.z;
+    memcpy(out->look_at, look_at, 12);
 }
 
 void orc_generate_ray(const rt_camera* cam, float ndc_x, float ndc_y, rt_ray* out)
@@ -1004,10 +1094,46 @@ void orc_render(const orc_bvh* b, const rt_camera* cam, const rt_features* f, co
                     prim[idx] = hit ? b->primitives[pos].id : -1;
             }
             if (rgb) {
-                c.rays_primary++;
+                // src/render.cpp:286-322. S = samples of this pixel; the area-light RNG key of
+                // sample s is pixel * S + s (== pixel on the plain path).
+                const bool ms = f->enableMultipleRaysPerPixel != 0, dof = f->enableDepthOfField != 0;
+                const int n = params->rays_per_pixel_side;
+                const uint32_t S = (ms ? (uint32_t)(n * n) : 0u) + (dof ? (uint32_t)params->samples_dof : 0u)
+                    + ((!ms && !dof) ? 1u : 0u);
+                const uint32_t pixel = (uint32_t)(y * W + x);
                 V3 colorSum = v3(0.f, 0.f, 0.f);
-                colorSum = colorSum + recursiveRayTrace(cx, cameraRay, params->depth, params->depth, 0);
-                V3 finalColor = colorSum / float(1);
+                size_t weight = 0;
+                const float pixelSizeX = 1 / float(W) * 2.f, pixelSizeY = 1 / float(H) * 2.f;
+                uint32_t s_index = 0;
+                if (ms) {
+                    V3 color = v3(0.f, 0.f, 0.f);
+                    for (const Ray& ray : getRaySamples(*cam, *params, pixel, px, py, pixelSizeX, pixelSizeY, n)) {
+                        c.rays_primary++;
+                        cx.pixel = pixel * S + s_index++;
+                        color = color + recursiveRayTrace(cx, ray, params->depth, params->depth, 0);
+                    }
+                    color = color / float(n * n);
+                    colorSum = colorSum + color;
+                    weight++;
+                }
+                if (dof) {
+                    V3 color = v3(0.f, 0.f, 0.f);
+                    for (const Ray& ray : getDOFRays(*cam, *params, pixel, px, py, params->focus_plane_distance,
+                             params->blur_strength, params->samples_dof)) {
+                        c.rays_primary++;
+                        cx.pixel = pixel * S + s_index++;
+                        color = color + recursiveRayTrace(cx, ray, params->depth, params->depth, 0);
+                    }
+                    color = color / float(params->samples_dof);
+                    colorSum = colorSum + color * 3.f;
+                    weight += 3;
+                }
+                if (!ms && !dof) {
+                    c.rays_primary++;
+                    colorSum = colorSum + recursiveRayTrace(cx, cameraRay, params->depth, params->depth, 0);
+                    weight++;
+                }
+                V3 finalColor = colorSum / float(weight);
                 rgb[3 * idx] = finalColor.x, rgb[3 * idx + 1] = finalColor.y, rgb[3 * idx + 2] = finalColor.z;
             }
         }
@@ -1019,6 +1145,43 @@ void orc_render(const orc_bvh* b, const rt_camera* cam, const rt_features* f, co
         total.sphere_tests += c.sphere_tests;
     }
     addCounters(counters, total);
+}
+
+// ≙ renderBloomFilter (src/render.cpp:157-196) on a full row-flipped W x H frame, in place.
+void orc_bloom(float* rgb, int32_t W, int32_t H, const rt_render_params* p)
+{
+    const size_t n = (size_t)W * H;
+    std::vector<V3> screenData(n), screenThreshold(n);
+    for (size_t i = 0; i < n; i++)
+        screenData[i] = screenThreshold[i] = v3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    for (size_t i = 0; i < n; i++) {
+        float brightness = (float)(0.2126 * screenThreshold[i].x + 0.7152 * screenThreshold[i].y + 0.0722 * screenThreshold[i].z);
+        // (the reference keeps `brightness` as float: `float brightness = <double expression>`)
+        if (brightness < p->bloom_threshold)
+            screenThreshold[i] = v3(0.0f, 0.0f, 0.0f);
+    }
+    auto indexAt = [&](int x, int y) { return (size_t)(H - 1 - y) * W + x; };
+    float w[3][3];
+    weightsGaussian(1.0f, w);
+    for (int y = 0; y < H - 1; y++) {
+        for (int x = 0; x < W - 1; x++) {
+            const size_t idx = indexAt(x, y);
+            V3 sum = v3(0.0f, 0.0f, 0.0f);
+            for (int k = -1; k < 2; k++) {
+                for (int j = -1; j < 2; j++) {
+                    if (!(x + k < 0 || x + k > W - 1 || y + j < 0 || y + j > H - 1)) {
+                        const size_t thisIndex = indexAt(x + k, y + j);
+                        const float weight = w[k + 1][j + 1];
+                        sum = sum + screenThreshold[thisIndex] * weight;
+                    }
+                }
+            }
+            const float scalar = p->bloom_scalar;
+            V3 newColor = screenData[idx] + sum * scalar;
+            V3 outc = p->bloom_debug_option == 0 ? newColor : (p->bloom_debug_option == 1 ? sum * scalar : screenData[idx]);
+            rgb[3 * idx] = outc.x, rgb[3 * idx + 1] = outc.y, rgb[3 * idx + 2] = outc.z;
+        }
+    }
 }
 
 // Single-function probes used to pin the restatement against oracle/_ref.

@@ -320,8 +320,7 @@ def test_unsupported_features_fail_loudly(rt, abi, scenes, built):
     data, sc, bvh, ob = built("cornell", f_ok)
     cam = rt.camera(*scenes.default_camera_args(32, 32))
     p = abi.RenderParams.make()
-    for flag in ("enableBloomEffect", "enableMultipleRaysPerPixel", "enableDepthOfField", "enableGlossyReflection",
-                 "enableTransparency"):
+    for flag in ("enableGlossyReflection", "enableTransparency"):  # the other extras: tests/test_gpu_extras.py
         f = abi.Features.make(enableShading=1, enableAccelStructure=1, **{flag: 1})
         with pytest.raises(capi.RtError) as e:
             rt.render(bvh, cam, f, p, 32, 32)
