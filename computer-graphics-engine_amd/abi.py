@@ -88,15 +88,18 @@ class RenderParams(C.Structure):
     _fields_ = [("depth", C.c_int32), ("parallelogram_n", C.c_int32), ("segment_n", C.c_int32), ("seed", C.c_uint32),
                 ("rays_per_pixel_side", C.c_int32), ("samples_dof", C.c_int32), ("focus_plane_distance", C.c_float),
                 ("blur_strength", C.c_float), ("bloom_scalar", C.c_float), ("bloom_threshold", C.c_float),
-                ("bloom_debug_option", C.c_int32)]
+                ("bloom_debug_option", C.c_int32), ("glossy_reflections_cap", C.c_int32),
+                ("rays_per_reflection", C.c_int32), ("alpha_modifier", C.c_float)]
 
     @classmethod
     def make(cls, depth=5, parallelogram_n=5, segment_n=25, seed=0, rays_per_pixel_side=3, samples_dof=5,
              focus_plane_distance=3.0, blur_strength=0.005, bloom_scalar=0.3, bloom_threshold=0.4,
-             bloom_debug_option=0) -> "RenderParams":
+             bloom_debug_option=0, glossy_reflections_cap=3, rays_per_reflection=40,
+             alpha_modifier=1.0) -> "RenderParams":
         """Defaults = the reference's globals (src/render.cpp:14-22, src/light.cpp:12-13)."""
         return cls(depth, parallelogram_n, segment_n, seed, rays_per_pixel_side, samples_dof, focus_plane_distance,
-                   blur_strength, bloom_scalar, bloom_threshold, bloom_debug_option)
+                   blur_strength, bloom_scalar, bloom_threshold, bloom_debug_option, glossy_reflections_cap,
+                   rays_per_reflection, alpha_modifier)
 
 
 class Counters(C.Structure):

@@ -201,6 +201,8 @@ uint32_t feature_flags(const rt_features& f)
     if (f.enableAccelStructure) fl |= rt::F_ACCEL;
     if (f.enableBilinearTextureFiltering) fl |= rt::F_BILINEAR;
     if (g_unpruned.load()) fl |= rt::F_NO_PRUNE;
+    if (f.enableTransparency) fl |= rt::F_TRANSPARENCY;
+    if (f.enableGlossyReflection) fl |= rt::F_GLOSSY;
     return fl;
 }
 

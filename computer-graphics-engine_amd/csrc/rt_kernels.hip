@@ -174,6 +174,103 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
     }
 }
 
+// bvh.intersect's HitInfo (bvh.cpp:365-426) and computeLightContribution (light.cpp:108-165) for the
+// lanes with `hit`: returns Lo (the albedo when shading is off); ALL lanes of the wave must call
+// (the shadow rays are traced by the whole wave).
+template <bool COUNT>
+RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int32_t pos, int32_t level, uint32_t pixel,
+    HitL& h, LaneCounters& lc, RayCounts& rc, WaveLds& wl)
+{
+    const SceneView& sv = a.sv;
+    const uint32_t flags = a.flags;
+    const bool use_bvh = (flags & F_ACCEL) != 0;
+    const bool prune = (flags & F_NO_PRUNE) == 0;
+    h.normal = mk(0, 0, 1), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
+    h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
+    if (hit)
+        resolve_hit(sv, flags, ray, t, pos, h);
+    if (COUNT && hit)
+        rc.hits = 1;
+
+    // ---- computeLightContribution (light.cpp:108-165) ---------------------------
+    V3 Lo = h.kd; // !enableShading: the albedo (light.cpp:161-164)
+    if (flags & F_SHADING) {
+        V3 result = mk(0.0f, 0.0f, 0.0f);
+        const LightRec RT_CONST_AS* lights = (const LightRec RT_CONST_AS*)sv.lights;
+        for (uint32_t li = 0; li < sv.n_lights; li++) {
+            const LightRec RT_CONST_AS* L = lights + li;
+            const int32_t kind = L->kind;
+            const bool is_point = kind == RT_LIGHT_POINT;
+            if (!is_point && !(flags & F_SOFT_SHADOW))
+                continue; // segment / parallelogram lights only contribute with soft shadows
+            const bool trace_shadow = is_point ? (flags & F_HARD_SHADOW) != 0 : true;
+            const int32_t n = a.parallelogram_n;
+            const int32_t nsamp = is_point ? 1 : (kind == RT_LIGHT_SEGMENT ? a.segment_n : n * n);
+            V3 acc = mk(0.0f, 0.0f, 0.0f);
+            for (int32_t s = 0; s < nsamp; s++) {
+                V3 lpos, lcol;
+                if (is_point) {
+                    lpos = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
+                    lcol = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
+                } else if (kind == RT_LIGHT_SEGMENT) { // sampleSegmentLight, light.cpp:19-26
+                    const V3 e0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]), e1 = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
+                    const V3 c0 = mk(L->v[2][0], L->v[2][1], L->v[2][2]), c1 = mk(L->v[3][0], L->v[3][1], L->v[3][2]);
+                    const float r = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
+                    const float weight = ((float)s + r) / (float)a.segment_n;
+                    lpos = (e1 - e0) * weight + e0;
+                    lcol = weight * c1 + (1 - weight) * c0;
+                } else { // sampleParallelogramLight, light.cpp:30-45
+                    const int32_t i = s / n, k = s - i * n;
+                    const V3 v0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
+                    const V3 e01 = mk(L->v[1][0], L->v[1][1], L->v[1][2]), e02 = mk(L->v[2][0], L->v[2][1], L->v[2][2]);
+                    const V3 c0 = mk(L->v[3][0], L->v[3][1], L->v[3][2]), c1 = mk(L->v[4][0], L->v[4][1], L->v[4][2]);
+                    const V3 c2 = mk(L->v[5][0], L->v[5][1], L->v[5][2]), c3 = mk(L->v[6][0], L->v[6][1], L->v[6][2]);
+                    const float horRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
+                    const float verRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 1u));
+                    const float horWeight = ((float)i + horRandom) / (float)n;
+                    const float verWeight = ((float)k + verRandom) / (float)n;
+                    const V3 horVector = horWeight * e01;
+                    const V3 verVector = verWeight * e02;
+                    lpos = v0 + horVector + verVector;
+                    const V3 bottomColor = horWeight * c1 + (1 - horWeight) * c0;
+                    const V3 topColor = horWeight * c3 + (1 - horWeight) * c2;
+                    lcol = verWeight * topColor + (1 - verWeight) * bottomColor;
+                }
+                float visibility = 1.0f;
+                if (trace_shadow) { // testVisibilityLightSample, light.cpp:49-73
+                    const RayL sray = shadow_ray(ray, t, lpos);
+                    float st = 1.0f;
+                    int32_t spos;
+                    if (COUNT && hit)
+                        rc.shadow++;
+                    if (!(flags & F_TRANSPARENCY)) {
+                        traverse<true, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
+                        if (spos >= 0)
+                            visibility = 0.0f;
+                    } else { // light.cpp:66-69: the CLOSEST blocker's material.transparency
+                        traverse<false, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
+                        if (spos >= 0)
+                            visibility = hit_transparency(sv, flags, spos);
+                    }
+                }
+                V3 color = mk(0.0f, 0.0f, 0.0f);
+                if (hit)
+                    color = compute_shading(lpos, lcol, ray, t, h);
+                if (is_point)
+                    result = result + color * visibility;
+                else
+                    acc = acc + color * visibility;
+            }
+            if (!is_point) {
+                const float denom = kind == RT_LIGHT_SEGMENT ? (float)a.segment_n : (float)n * (float)n;
+                result = result + acc / denom;
+            }
+        }
+        Lo = result;
+    }
+    return Lo;
+}
+
 // agent-scope relaxed accesses to the work-sharing words (one lane)
 RT_DEV uint32_t sh_load(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RT_DEV uint32_t sh_add(uint32_t* p, uint32_t v)
@@ -313,83 +410,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     }
 
     HitL h;
-    h.normal = mk(0, 0, 1), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
-    h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
-    if (hit)
-        resolve_hit(sv, flags, ray, t, pos, h);
-    if (COUNT && hit)
-        rc.hits = 1;
-
-    // ---- computeLightContribution (light.cpp:108-165) ---------------------------
-    V3 Lo = h.kd; // !enableShading: the albedo (light.cpp:161-164)
-    if (flags & F_SHADING) {
-        V3 result = mk(0.0f, 0.0f, 0.0f);
-        const LightRec RT_CONST_AS* lights = (const LightRec RT_CONST_AS*)sv.lights;
-        for (uint32_t li = 0; li < sv.n_lights; li++) {
-            const LightRec RT_CONST_AS* L = lights + li;
-            const int32_t kind = L->kind;
-            const bool is_point = kind == RT_LIGHT_POINT;
-            if (!is_point && !(flags & F_SOFT_SHADOW))
-                continue; // segment / parallelogram lights only contribute with soft shadows
-            const bool trace_shadow = is_point ? (flags & F_HARD_SHADOW) != 0 : true;
-            const int32_t n = a.parallelogram_n;
-            const int32_t nsamp = is_point ? 1 : (kind == RT_LIGHT_SEGMENT ? a.segment_n : n * n);
-            V3 acc = mk(0.0f, 0.0f, 0.0f);
-            for (int32_t s = 0; s < nsamp; s++) {
-                V3 lpos, lcol;
-                if (is_point) {
-                    lpos = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
-                    lcol = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
-                } else if (kind == RT_LIGHT_SEGMENT) { // sampleSegmentLight, light.cpp:19-26
-                    const V3 e0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]), e1 = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
-                    const V3 c0 = mk(L->v[2][0], L->v[2][1], L->v[2][2]), c1 = mk(L->v[3][0], L->v[3][1], L->v[3][2]);
-                    const float r = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
-                    const float weight = ((float)s + r) / (float)a.segment_n;
-                    lpos = (e1 - e0) * weight + e0;
-                    lcol = weight * c1 + (1 - weight) * c0;
-                } else { // sampleParallelogramLight, light.cpp:30-45
-                    const int32_t i = s / n, k = s - i * n;
-                    const V3 v0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
-                    const V3 e01 = mk(L->v[1][0], L->v[1][1], L->v[1][2]), e02 = mk(L->v[2][0], L->v[2][1], L->v[2][2]);
-                    const V3 c0 = mk(L->v[3][0], L->v[3][1], L->v[3][2]), c1 = mk(L->v[4][0], L->v[4][1], L->v[4][2]);
-                    const V3 c2 = mk(L->v[5][0], L->v[5][1], L->v[5][2]), c3 = mk(L->v[6][0], L->v[6][1], L->v[6][2]);
-                    const float horRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
-                    const float verRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 1u));
-                    const float horWeight = ((float)i + horRandom) / (float)n;
-                    const float verWeight = ((float)k + verRandom) / (float)n;
-                    const V3 horVector = horWeight * e01;
-                    const V3 verVector = verWeight * e02;
-                    lpos = v0 + horVector + verVector;
-                    const V3 bottomColor = horWeight * c1 + (1 - horWeight) * c0;
-                    const V3 topColor = horWeight * c3 + (1 - horWeight) * c2;
-                    lcol = verWeight * topColor + (1 - verWeight) * bottomColor;
-                }
-                float visibility = 1.0f;
-                if (trace_shadow) { // testVisibilityLightSample, light.cpp:49-73
-                    const RayL sray = shadow_ray(ray, t, lpos);
-                    float st = 1.0f;
-                    int32_t spos;
-                    if (COUNT && hit)
-                        rc.shadow++;
-                    traverse<true, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
-                    if (spos >= 0)
-                        visibility = 0.0f;
-                }
-                V3 color = mk(0.0f, 0.0f, 0.0f);
-                if (hit)
-                    color = compute_shading(lpos, lcol, ray, t, h);
-                if (is_point)
-                    result = result + color * visibility;
-                else
-                    acc = acc + color * visibility;
-            }
-            if (!is_point) {
-                const float denom = kind == RT_LIGHT_SEGMENT ? (float)a.segment_n : (float)n * (float)n;
-                result = result + acc / denom;
-            }
-        }
-        Lo = result;
-    }
+    const V3 Lo = shade_hit<COUNT>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl);
     if (hit) {
         float* d = a.direct + (size_t)(level - first_level) * a.level_stride + 3 * (size_t)item;
         d[0] = Lo.x, d[1] = Lo.y, d[2] = Lo.z;

@@ -16,6 +16,8 @@ enum : uint32_t {
     F_ACCEL = 1u << 6,
     F_BILINEAR = 1u << 7,
     F_NO_PRUNE = 1u << 8, // reference policy: visit every leaf whose boxes are hit (rt_set_option "unpruned")
+    F_TRANSPARENCY = 1u << 9, // extra.enableTransparency (render.cpp:36-49,108-111; light.cpp:66-69)
+    F_GLOSSY = 1u << 10,      // extra.enableGlossyReflection (render.cpp:56-99)
 };
 
 struct HitL { // one lane's HitInfo (src/common.h:14-19) without the unused members
@@ -76,6 +78,13 @@ RT_DEV V3 acquire_texel(const SceneView& sv, int32_t tex, float u, float v, bool
     const V3 x1 = (1 - xSplit) * xdyd + xSplit * xuyd;
     const V3 x2 = (1 - xSplit) * xdyu + xSplit * xuyu;
     return (1 - ySplit) * x1 + ySplit * x2;
+}
+
+// material.transparency of the primitive at array position `pos` (shadow rays with enableTransparency)
+RT_DEV float hit_transparency(const SceneView& sv, uint32_t flags, int32_t pos)
+{
+    const PrimRecord* rec = ((flags & F_ACCEL) ? sv.prims : sv.prims_flat) + pos;
+    return sv.materials[rec->kind_mat & 0x7fffffffu].transparency;
 }
 
 // Hit attribute resolution — src/bounding_volume_hierarchy.cpp:365-426.

@@ -283,14 +283,21 @@ struct Walk {
     // On entry lanes with `seed` hold one entry (node pair `node`, own ray, bound lb).
     RT_DEV void lane_engine(uint32_t row0, bool seed, uint32_t node, float seed_lb)
     {
-        uint32_t bot = 0, sp = 0; // this lane's deque = rows row0 + [bot .. sp)
-        if (seed) {
-            L.stack[row0][lane] = pack_entry(node, lane, seed_lb);
-            sp = 1;
-        }
-        wave_lds_fence();
+        // The lane's CURRENT entry lives in a register; its deque in LDS (rows row0 + [bot .. sp))
+        // holds only what it has put aside (far children) — that is what thieves take.
+        uint32_t bot = 0, sp = 0;
+        bool have = seed;
+        uint32_t e = seed ? pack_entry(node, lane, seed_lb) : 0u;
         for (;;) {
-            const uint64_t busy = ballot(sp > bot);
+            // lanes without a current entry take the newest one of their own deque
+            if (!have && sp > bot) {
+                sp--;
+                e = L.stack[row0 + sp][lane];
+                if (sp == bot)
+                    sp = bot = 0;
+                have = true;
+            }
+            const uint64_t busy = ballot(have);
             if (busy == 0)
                 break;
 #ifdef RT_TIMELINE
@@ -299,29 +306,29 @@ struct Walk {
 #ifdef RT_STAMPS
             const unsigned long long ts0 = clock64();
 #endif
-            if (busy != ~0ull) { // steal: idle lanes take the oldest entry of lanes holding >= 2
-                const bool donor = sp - bot >= 2u;
+            if (busy != ~0ull) { // steal: idle lanes take the OLDEST deque entry (largest subtree) of a busy lane
+                const bool donor = sp > bot;
                 const uint64_t donors = ballot(donor);
                 if (donors) {
                     const uint64_t idle = ~busy;
                     const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
                     const uint32_t n_don = (uint32_t)__builtin_popcountll(donors);
                     const uint32_t n_x = n_idle < n_don ? n_idle : n_don;
-                    const bool is_idle = sp == bot;
                     if (donor) {
                         const uint32_t k = prefix_count(donors);
                         if (k < n_x) {
                             L.xfer[k] = L.stack[row0 + bot][lane];
                             bot++;
+                            if (sp == bot)
+                                sp = bot = 0;
                         }
                     }
                     wave_lds_fence();
-                    if (is_idle) {
+                    if (!have) {
                         const uint32_t k = prefix_count(idle);
                         if (k < n_x) {
-                            L.stack[row0][lane] = L.xfer[k];
-                            bot = 0;
-                            sp = 1;
+                            e = L.xfer[k];
+                            have = true;
                         }
                     }
                     wave_lds_fence();
@@ -334,21 +341,13 @@ struct Walk {
             bool leaf_l = false, leaf_r = false;
             uint32_t l_ref = 0, l_cnt = 0, r_ref = 0, r_cnt = 0, r = 0;
             float lb_l = 0.0f, lb_r = 0.0f;
-            if (sp > bot) {
-                sp--;
-                const uint32_t e = L.stack[row0 + sp][lane];
+            if (have) {
+                have = false;
                 const float e_lb = entry_lb(e);
-                if (sp == bot)
-                    sp = bot = 0;
                 r = entry_ray(e);
                 const bool skip = ANY ? (L.best[r] != kNoHit) : (prune && e_lb > ray_limit(L, r));
                 if (!skip) {
                     load_ray(r);
-#ifdef RT_STAMPS
-                    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the pop and the ray reads are back
-                    const unsigned long long tp = clock64();
-                    st_pop += tp - ts1;
-#endif
                     const uint32_t noff = entry_node(e) * 64u;
                     const float4 q0 = buf_load16(nodes, noff);       // l_lo xyz, l_hi x
                     const float4 q1 = buf_load16(nodes, noff + 16u); // l_hi yz, r_lo xy
@@ -366,11 +365,6 @@ struct Walk {
                     const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
                     const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
                     bool hl, hr;
-#ifdef RT_STAMPS
-                    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the node's four quads are back
-                    const unsigned long long tl = clock64();
-                    st_load += tl - tp;
-#endif
                     test_pair(llo, lhi, rlo, rhi, r, hl, hr, lb_l, lb_r);
 #if defined(RT_DIAG) && RT_DIAG == 3 // the slab arithmetic once more (children swapped), result unused
                     {
@@ -383,29 +377,22 @@ struct Walk {
                         asm volatile("" ::"v"(yl), "v"(yr), "v"((int)xl), "v"((int)xr));
                     }
 #endif
-#ifdef RT_STAMPS
-                    asm volatile("" ::"v"(lb_l), "v"(lb_r));
-                    const unsigned long long ta = clock64();
-                    st_alu += ta - tl;
-#endif
                     l_ref = q3.x, l_cnt = q3.y, r_ref = q3.z, r_cnt = q3.w;
                     const bool push_l = hl && l_cnt == 0u, push_r = hr && r_cnt == 0u;
-                    // the nearer child goes on top (popped first): finds close hits early
+                    // the nearer child becomes the current entry (finds close hits early), the
+                    // farther one is put aside
                     const uint32_t e_l = pack_entry(l_ref, r, lb_l), e_r = pack_entry(r_ref, r, lb_r);
                     const bool both = push_l && push_r, l_far = lb_l > lb_r;
-                    if (push_l || push_r) {
-                        L.stack[row0 + sp][lane] = both ? (l_far ? e_l : e_r) : (push_l ? e_l : e_r);
+                    if (both) {
+                        L.stack[row0 + sp][lane] = l_far ? e_l : e_r;
                         sp++;
                     }
-                    if (both) {
-                        L.stack[row0 + sp][lane] = l_far ? e_r : e_l;
-                        sp++;
+                    if (push_l || push_r) {
+                        e = both ? (l_far ? e_r : e_l) : (push_l ? e_l : e_r);
+                        have = true;
                     }
                     leaf_l = hl && l_cnt != 0u; // l_cnt / r_cnt: count words (rt_layout.h)
                     leaf_r = hr && r_cnt != 0u;
-#ifdef RT_STAMPS
-                    st_push += clock64() - ta;
-#endif
                 }
             }
             queue_leaves(leaf_l, r, l_ref, l_cnt, lb_l);

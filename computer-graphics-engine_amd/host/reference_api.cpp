@@ -19,6 +19,9 @@ float blurStrength = .005f;       // :17
 float bloomScalar = .3f;          // :19
 float bloomThreshold = .4f;       // :20
 int bloomDebugOption = 0;         // :21
+int glossyReflectionsCap = 3;     // :23
+int raysPerReflection = 40;       // :24
+float alphaModifier = 1.f;        // :25
 
 namespace {
 
@@ -74,6 +77,9 @@ rt_render_params params_for(int depth)
     p.bloom_scalar = bloomScalar;
     p.bloom_threshold = bloomThreshold;
     p.bloom_debug_option = bloomDebugOption;
+    p.glossy_reflections_cap = glossyReflectionsCap;
+    p.rays_per_reflection = raysPerReflection;
+    p.alpha_modifier = alphaModifier;
     return p;
 }
 

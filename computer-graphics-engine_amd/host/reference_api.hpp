@@ -211,6 +211,9 @@ extern int raysPerPixelSide;
 extern int samplesDoF;
 extern float focusPlaneDistance;
 extern float blurStrength;
+extern int raysPerReflection;
+extern float alphaModifier;
+extern int glossyReflectionsCap; // file-local in the reference (src/render.cpp:23); exposed here for tests
 
 // src/render.h:32,35
 void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features);

@@ -114,7 +114,7 @@ int main(int argc, char** argv)
 
     const float deg = 0.01745329251994329576923690768489f; // glm::radians
     std::vector<float> frame((size_t)W * H * 3);
-    const rt_render_params params { depth, 5, 25, 0, 3, 5, 3.0f, 0.005f, 0.3f, 0.4f, 0 }; // the reference's defaults
+    const rt_render_params params { depth, 5, 25, 0, 3, 5, 3.0f, 0.005f, 0.3f, 0.4f, 0, 3, 40, 1.0f }; // the reference's defaults
     const auto r0 = clock::now();
     for (size_t i = 0; i < cams.size(); i++) {
         rt_camera cam;

@@ -166,6 +166,9 @@ typedef struct rt_render_params {
     float bloom_scalar;           /* bloomScalar (.3f): enableBloomEffect */
     float bloom_threshold;        /* bloomThreshold (.4f) */
     int32_t bloom_debug_option;   /* bloomDebugOption (0 = final image, 1 = bloom only, else unfiltered) */
+    int32_t glossy_reflections_cap; /* glossyReflectionsCap (3): enableGlossyReflection */
+    int32_t rays_per_reflection;  /* raysPerReflection (40) */
+    float alpha_modifier;         /* alphaModifier (1.f) */
 } rt_render_params;
 
 /* ---- ray / test counters of one call (what SURVEY.md §8(d) prices) ------- */

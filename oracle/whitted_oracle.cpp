@@ -612,6 +612,7 @@ struct TraceCtx {
     rt_render_params params;
     uint32_t pixel;
     Counters* c;
+    uint32_t draws = 0; // glossy sample counter of the current pixel sample (reset per primary ray)
 };
 
 // ---------------------------------------------------------------------------
@@ -702,28 +703,102 @@ V3 computeLightContribution(TraceCtx& cx, const Ray& ray, const HitInfo& hitInfo
 }
 
 // ---------------------------------------------------------------------------
-// src/render.cpp:27-155 — plain Whitted path. The glossy / enableTransparency
-// extras are outside the hot-path scope (callers reject those flags). The
-// `material.transparency != 1` branch of :122-130 IS restated (it runs
-// whenever enableRecursive is set, whatever enableTransparency says).
+// src/render.cpp:27-155 — recursiveRayTrace with every branch: plain Whitted path,
+// enableTransparency without recursion (:36-49), glossy reflections (:56-99), the
+// `material.transparency != 1` branch (:108-130, it runs whenever enableRecursive is set and
+// glossy is off, whatever enableTransparency says).
+// Deviations, shared with the device path so that the parity tests compare like with like:
+//  * glossy samples: rand() (irreproducible under OpenMP) → rt_rand31 stream 61 keyed by the
+//    pixel and a per-pixel draw counter that advances in the reference's call order;
+//  * recursion guard: the `vec = recursiveRayTrace(..., rayDepth - 1, ...)` call of :122 has no
+//    depth test; frames deeper than params.depth + kExtraFrames return vec3(0) (the reference
+//    would keep recursing while rays keep hitting non-opaque surfaces).
 // ---------------------------------------------------------------------------
+constexpr int kExtraFrames = 10;
+constexpr uint32_t kStreamGlossy = 61;
+
 V3 recursiveRayTrace(TraceCtx& cx, Ray ray, int rayDepth, int rayDepthInitial, int guard)
 {
     HitInfo hitInfo;
-    if (guard > 4096) // the reference would overflow its stack here
+    if (guard > rayDepthInitial + kExtraFrames)
         return v3(0, 0, 0);
-    uint32_t level = (uint32_t)(rayDepthInitial - rayDepth);
+    uint32_t level = (uint32_t)(rayDepthInitial - rayDepth); // rt_rand31 keeps its low 6 bits
     if (bvhIntersect(cx.bvh, ray, hitInfo, cx.f, *cx.c, nullptr)) {
         V3 Lo = computeLightContribution(cx, ray, hitInfo, level);
         Ray reflection = computeReflectionRay(ray, hitInfo);
+
+        if (cx.f.enableTransparency && !cx.f.enableRecursive && !cx.f.enableGlossyReflection) { // :36-49
+            if (hitInfo.material.transparency == 1.0f || rayDepth <= 0)
+                return Lo;
+            Lo = Lo * hitInfo.material.transparency;
+            Ray t;
+            t.origin = (0.00001f + ray.t) * ray.direction + ray.origin;
+            t.direction = ray.direction;
+            t.t = FLT_MAX;
+            HitInfo h;
+            h.normal = hitInfo.normal;
+            bvhIntersect(cx.bvh, t, h, cx.f, *cx.c, nullptr); // leaves the hit distance in t.t, which the callee gets
+            Lo = Lo + (1.0f - hitInfo.material.transparency) * recursiveRayTrace(cx, t, rayDepth - 1, rayDepthInitial, guard + 1);
+        }
+
         if (!(isSentinel(reflection) || rayDepth < 1)) {
             if (cx.f.enableRecursive) {
-                cx.c->rays_reflect++;
-                Lo = Lo + recursiveRayTrace(cx, reflection, rayDepth - 1, rayDepthInitial, guard + 1);
+                V3 originalDirection = reflection.direction;
+                if (cx.f.enableGlossyReflection && hitInfo.material.shininess != 0) { // :57-96
+                    V3 w = normalize(originalDirection);
+                    V3 t = w;
+                    float mn = t.x;
+                    int minIdx = 0;
+                    if (t.y < mn) {
+                        mn = t.y;
+                        minIdx = 1;
+                    }
+                    if (t.z < mn) {
+                        mn = t.z;
+                        minIdx = 2;
+                    }
+                    (minIdx == 0 ? t.x : (minIdx == 1 ? t.y : t.z)) = 1.0f;
+                    V3 u = cross(t, w) / length(cross(t, w));
+                    V3 v = cross(w, u);
+                    float a = (1 / hitInfo.material.shininess) * cx.params.alpha_modifier;
+                    V3 totalColor = v3(.0f, .0f, .0f);
+                    for (int i = 0; i < cx.params.rays_per_reflection; i++) {
+                        float randOne = rand01(rand31(cx.params.seed, cx.pixel, kStreamGlossy, 0, cx.draws & 0x1ffffu, 0));
+                        float randTwo = rand01(rand31(cx.params.seed, cx.pixel, kStreamGlossy, 0, cx.draws & 0x1ffffu, 1));
+                        cx.draws++;
+                        float weightU = -a / 2 + randOne * a;
+                        float weightV = -a / 2 + randTwo * a;
+                        V3 glossReflection = w + weightU * u + weightV * v;
+                        glossReflection = normalize(glossReflection);
+                        if (dot(hitInfo.normal, glossReflection) > 0) {
+                            Ray glossRay;
+                            glossRay.origin = reflection.origin;
+                            glossRay.direction = glossReflection;
+                            glossRay.t = FLT_MAX;
+                            cx.c->rays_reflect++;
+                            int d = rayDepth - 1 < cx.params.glossy_reflections_cap ? rayDepth - 1 : cx.params.glossy_reflections_cap;
+                            V3 color = recursiveRayTrace(cx, glossRay, d, rayDepthInitial, guard + 1);
+                            totalColor = totalColor + color * hitInfo.material.ks;
+                        }
+                    }
+                    totalColor = totalColor / float(cx.params.rays_per_reflection);
+                    Lo = Lo + totalColor;
+                } else {
+                    cx.c->rays_reflect++;
+                    Lo = Lo + recursiveRayTrace(cx, reflection, rayDepth - 1, rayDepthInitial, guard + 1);
+                }
             }
         }
-        if (cx.f.enableRecursive) {
-            Ray reflection2 = computeReflectionRay(ray, hitInfo);
+
+        if (cx.f.enableRecursive && !cx.f.enableGlossyReflection) { // :101-130
+            Ray reflection2;
+            if (cx.f.enableTransparency && hitInfo.material.transparency != 1.0f) {
+                reflection2.origin = (0.00001f + ray.t) * ray.direction + ray.origin;
+                reflection2.direction = ray.direction;
+                reflection2.t = FLT_MAX;
+            } else {
+                reflection2 = computeReflectionRay(ray, hitInfo);
+            }
             if (!isSentinel(reflection2)) {
                 if (rayDepth > 0) {
                     cx.c->rays_reflect++;
@@ -1045,6 +1120,7 @@ void orc_trace_batch(const orc_bvh* b, const rt_ray* rays, uint32_t n, const uin
         r.t = rays[i].t;
         cx.pixel = pixel_ids ? pixel_ids[i] : i;
         c.rays_primary++;
+        cx.draws = 0;
         V3 col = recursiveRayTrace(cx, r, params->depth, params->depth, 0);
         rgb[3 * i] = col.x, rgb[3 * i + 1] = col.y, rgb[3 * i + 2] = col.z;
     }
@@ -1110,6 +1186,7 @@ void orc_render(const orc_bvh* b, const rt_camera* cam, const rt_features* f, co
                     for (const Ray& ray : getRaySamples(*cam, *params, pixel, px, py, pixelSizeX, pixelSizeY, n)) {
                         c.rays_primary++;
                         cx.pixel = pixel * S + s_index++;
+                        cx.draws = 0;
                         color = color + recursiveRayTrace(cx, ray, params->depth, params->depth, 0);
                     }
                     color = color / float(n * n);
@@ -1122,6 +1199,7 @@ void orc_render(const orc_bvh* b, const rt_camera* cam, const rt_features* f, co
                              params->blur_strength, params->samples_dof)) {
                         c.rays_primary++;
                         cx.pixel = pixel * S + s_index++;
+                        cx.draws = 0;
                         color = color + recursiveRayTrace(cx, ray, params->depth, params->depth, 0);
                     }
                     color = color / float(params->samples_dof);
@@ -1130,6 +1208,7 @@ void orc_render(const orc_bvh* b, const rt_camera* cam, const rt_features* f, co
                 }
                 if (!ms && !dof) {
                     c.rays_primary++;
+                    cx.draws = 0;
                     colorSum = colorSum + recursiveRayTrace(cx, cameraRay, params->depth, params->depth, 0);
                     weight++;
                 }
