@@ -90,6 +90,7 @@ struct Scratch {
     std::vector<int32_t> rows_host;
     DevBuf<uint32_t> order; // tile dispatch order (tile_order_for)
     DevBuf<float> samples;   // per-sample colours of multi-sample frames (k_resolve input)
+    DevBuf<float> frames;    // k_trace_general: per-wave-slot recursion frames
     DevBuf<float> bloom_src; // the frame before the bloom filter
     // tail work sharing of fused launches (rt_kernels.h ShareArgs)
     DevBuf<uint32_t> share_sched;
@@ -213,14 +214,7 @@ int check_features(const rt_features* f, const rt_bvh* bvh)
 {
     if (!f)
         return fail(RT_ERR_INVALID, "features == NULL");
-    if (f->enableGlossyReflection)
-        return fail(RT_ERR_UNSUPPORTED, "enableGlossyReflection (render.cpp:56-99) is outside the hot-path scope");
-    if (f->enableTransparency)
-        return fail(RT_ERR_UNSUPPORTED, "enableTransparency (render.cpp:36-49,108-111) is outside the hot-path scope");
-    if (f->enableRecursive && bvh->scene->host.any_non_opaque)
-        return fail(RT_ERR_UNSUPPORTED,
-            "enableRecursive with a material whose transparency != 1 takes the un-depth-limited branch of "
-            "render.cpp:122-130, which is outside the hot-path scope");
+    (void)bvh;
     return RT_OK;
 }
 
@@ -362,7 +356,39 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.state = sc.state.p;
     a.n_items = n_items;
     a.counters = counters_dev;
-    for (int32_t level = 0; level <= std::min(fused_from, n_levels - 1); level++) {
+    // recursiveRayTrace's branching variants (render.cpp:36-49 transparency chain, :56-99 glossy,
+    // :101-130 non-opaque materials under enableRecursive) run as per-lane state machines
+    const bool general = f.enableGlossyReflection || f.enableTransparency
+        || (f.enableRecursive && bvh->scene->host.any_non_opaque);
+    if (general) {
+        if (f.enableGlossyReflection && (p.rays_per_reflection < 1 || p.rays_per_reflection > 4096 || p.glossy_reflections_cap < 0))
+            return fail(RT_ERR_INVALID, "rays_per_reflection must be in [1, 4096], glossy_reflections_cap >= 0");
+        a.level = 0, a.fused = 0;
+        a.depth = p.depth;
+        a.direct = sc.direct.p;
+        a.source = source, a.in = user_rays, a.in_count = nullptr, a.in_count_imm = n_items;
+        a.max_frames = p.depth + rt::kExtraFrames + 1;
+        a.glossy_cap = p.glossy_reflections_cap, a.rays_per_reflection = p.rays_per_reflection;
+        a.alpha_modifier = p.alpha_modifier;
+        const uint32_t waves = rt::trace_general_waves(a);
+        HIP_TRY(sc.frames.reserve((size_t)waves * 64 * (size_t)a.max_frames * rt::kFrameWords));
+        a.frames = sc.frames.p;
+        if (bvh->profile) {
+            if (sc.events_used == sc.events.size()) {
+                hipEvent_t e0, e1;
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventCreate(&e1));
+                sc.events.emplace_back(e0, e1);
+            }
+            HIP_TRY(hipEventRecord(sc.events[sc.events_used].first, stream));
+        }
+        rt::launch_trace_general(a, counters_dev != nullptr, stream);
+        if (bvh->profile) {
+            HIP_TRY(hipEventRecord(sc.events[sc.events_used].second, stream));
+            sc.events_used++;
+        }
+    }
+    for (int32_t level = 0; !general && level <= std::min(fused_from, n_levels - 1); level++) {
         a.level = level;
         a.fused = level == fused_from ? 1u : 0u;
         a.direct = sc.direct.p + (size_t)level * n_items * 3;

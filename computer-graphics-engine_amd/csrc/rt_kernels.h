@@ -74,7 +74,15 @@ struct LevelArgs {
     uint32_t* state; // per item: bits 0..7 = levels that hit, bit 8 = chain ended on a miss
     uint32_t n_items;
     rt_counters* counters; // NULL unless counting build
+    // k_trace_general (transparency / glossy recursion): per-lane frame stacks, the extras' parameters
+    float* frames;
+    int32_t max_frames; // depth + kExtraFrames + 1
+    int32_t glossy_cap, rays_per_reflection;
+    float alpha_modifier;
 };
+
+constexpr int32_t kExtraFrames = 10; // frames past `depth` for the un-depth-limited call of render.cpp:122 (oracle: same)
+constexpr int32_t kFrameWords = 40;
 
 struct FoldArgs {
     const float* direct; // (depth + 1) level slices of n_items * 3
@@ -129,6 +137,8 @@ void set_diag_leaf(const float4* p);
 #endif
 uint32_t trace_level_groups(const LevelArgs& a); // workgroups launch_trace_level will start
 void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s);
+uint32_t trace_general_waves(const LevelArgs& a); // persistent waves of launch_trace_general (frame stacks are per wave slot)
+void launch_trace_general(const LevelArgs& a, bool count, hipStream_t s);
 void launch_fold(const FoldArgs& a, hipStream_t s);
 void launch_resolve(const ResolveArgs& a, hipStream_t s);
 void launch_bloom(const BloomArgs& a, hipStream_t s);

@@ -285,6 +285,331 @@ constexpr uint32_t kShareMinRays = 4;      // never split below this many rays p
 constexpr uint32_t kShareMaxParts = 4;     // one wave hands out at most three packets per level
 constexpr uint32_t kShareSpinLimit = 1u << 18;
 
+
+// ---------------------------------------------------------------------------------------------
+// k_trace_general — recursiveRayTrace (src/render.cpp:27-147) with ALL its branches: the
+// transparency-only chain (:36-49), glossy reflections (:56-99) and the `transparency != 1`
+// branch (:101-130). The fused level loop of k_trace_level follows ONE continuation per level;
+// these branches make up to three calls per invocation (or raysPerReflection of them), so every
+// lane runs the recursion as an explicit state machine with its frames in global memory, and the
+// wave traces one pending ray per lane per step. Same float operations in the same order as the
+// oracle; glossy samples from rt_rand31 stream 61 keyed by the pixel and a draw counter.
+// Used only when those flags / materials are present — the plain path stays in k_trace_level.
+// ---------------------------------------------------------------------------------------------
+enum : int32_t { GS_A, GS_B, GS_BG, GS_C, GS_C2, GS_END, GS_RET, GS_RESUME, GS_DONE };
+
+struct GFrame {
+    V3 Lo, ks, normal, total, w, u, v, gorigin, r2o, r2d;
+    float transp, shin, a, r2t;
+    int32_t depth, pc, gi, valid2;
+};
+RT_DEV void gframe_store(float* f, const GFrame& x)
+{
+    const float v[kFrameWords] = { x.Lo.x, x.Lo.y, x.Lo.z, x.ks.x, x.ks.y, x.ks.z, x.normal.x, x.normal.y, x.normal.z,
+        x.total.x, x.total.y, x.total.z, x.w.x, x.w.y, x.w.z, x.u.x, x.u.y, x.u.z, x.v.x, x.v.y, x.v.z, x.gorigin.x,
+        x.gorigin.y, x.gorigin.z, x.r2o.x, x.r2o.y, x.r2o.z, x.r2d.x, x.r2d.y, x.r2d.z, x.transp, x.shin, x.a, x.r2t,
+        __int_as_float(x.depth), __int_as_float(x.pc), __int_as_float(x.gi), __int_as_float(x.valid2), 0.0f, 0.0f };
+#pragma unroll
+    for (int i = 0; i < kFrameWords; i++)
+        f[i] = v[i];
+}
+RT_DEV void gframe_load(const float* f, GFrame& x)
+{
+    float v[kFrameWords];
+#pragma unroll
+    for (int i = 0; i < kFrameWords; i++)
+        v[i] = f[i];
+    x.Lo = mk(v[0], v[1], v[2]), x.ks = mk(v[3], v[4], v[5]), x.normal = mk(v[6], v[7], v[8]);
+    x.total = mk(v[9], v[10], v[11]), x.w = mk(v[12], v[13], v[14]), x.u = mk(v[15], v[16], v[17]);
+    x.v = mk(v[18], v[19], v[20]), x.gorigin = mk(v[21], v[22], v[23]), x.r2o = mk(v[24], v[25], v[26]);
+    x.r2d = mk(v[27], v[28], v[29]), x.transp = v[30], x.shin = v[31], x.a = v[32], x.r2t = v[33];
+    x.depth = __float_as_int(v[34]), x.pc = __float_as_int(v[35]), x.gi = __float_as_int(v[36]);
+    x.valid2 = __float_as_int(v[37]);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(const LevelArgs a)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t slot = uni(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t n_slots = gridDim.x * (kBlock / 64);
+    const SceneView& sv = a.sv;
+    const uint32_t flags = a.flags;
+    const bool use_bvh = (flags & F_ACCEL) != 0, prune = (flags & F_NO_PRUNE) == 0;
+    const bool fR = (flags & F_RECURSIVE) != 0, fT = (flags & F_TRANSPARENCY) != 0, fG = (flags & F_GLOSSY) != 0;
+    __shared__ WaveLds lds[kBlock / 64];
+    WaveLds& wl = lds[threadIdx.x >> 6];
+    float* const my_frames = a.frames + ((size_t)slot * 64u + lane) * (size_t)a.max_frames * kFrameWords;
+    uint32_t n_units;
+    if (a.source == SRC_CAMERA) {
+        const uint32_t tw = 1u << a.cam.tile_wlog, th = 1u << a.cam.tile_hlog;
+        n_units = (((uint32_t)a.cam.vwidth + tw - 1u) >> a.cam.tile_wlog) * (((uint32_t)a.cam.n_rows + th - 1u) >> a.cam.tile_hlog);
+    } else {
+        n_units = (a.in_count_imm + 63u) / 64u;
+    }
+    for (uint32_t unit = slot; unit < n_units; unit += n_slots) {
+        // ---- this lane's primary ray ------------------------------------------------------
+        bool active = false;
+        RayL ray;
+        ray.o = mk(0, 0, 0), ray.d = mk(0, 0, -1);
+        float tlim = kFltMax;
+        uint32_t item = 0, pixel = 0;
+        if (a.source == SRC_CAMERA) {
+            int32_t x, y, lrow;
+            active = tile_pixel(a.cam, unit, lane, x, y, lrow);
+            if (active) {
+                ray = camera_ray(a.cam, x, y);
+                item = (uint32_t)lrow * (uint32_t)a.cam.vwidth + (uint32_t)x;
+                pixel = (uint32_t)y * (uint32_t)a.cam.vwidth + (uint32_t)x;
+            }
+        } else {
+            const uint32_t i = unit * 64u + lane;
+            active = i < a.in_count_imm;
+            if (active) {
+                const float* q = a.in.ray;
+                const size_t cap = a.in.cap;
+                ray.o = mk(q[i], q[cap + i], q[2 * cap + i]);
+                ray.d = mk(q[3 * cap + i], q[4 * cap + i], q[5 * cap + i]);
+                if (a.in.t)
+                    tlim = a.in.t[i];
+                item = a.in.item ? a.in.item[i] : i;
+                pixel = a.in.pixel ? a.in.pixel[i] : i;
+            }
+        }
+        if (ballot(active) == 0)
+            continue;
+        int32_t op = active ? 1 : 0; // 0 none, 1 trace + shade (a recursiveRayTrace invocation), 2 probe
+        int32_t rayDepth = a.depth, sp = 0;
+        uint32_t draws = 0;
+        V3 result = mk(0.0f, 0.0f, 0.0f);
+        for (;;) {
+            const bool want = op != 0;
+            if (ballot(want) == 0)
+                break;
+            LaneCounters lc;
+            RayCounts rc;
+            if (COUNT && want)
+                rc.closest = 1;
+            float t = tlim;
+            int32_t pos;
+            traverse<false, COUNT>(sv, use_bvh, prune, want, ray, t, pos, lc, wl);
+            const bool full = op == 1;
+            const bool hit = full && pos >= 0;
+            const int32_t level = a.depth - rayDepth;
+            HitL h;
+            const V3 Lo0 = shade_hit<COUNT>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl);
+            if (COUNT && hit)
+                rc.hits = 1;
+            if (COUNT)
+                flush_counters(a.counters, lc, rc, 0, lane);
+            int32_t stage = GS_DONE;
+            V3 val = mk(0.0f, 0.0f, 0.0f);
+            GFrame fv;
+            fv.Lo = Lo0, fv.ks = h.ks, fv.normal = h.normal, fv.total = mk(0, 0, 0), fv.w = fv.u = fv.v = mk(0, 0, 0);
+            fv.gorigin = mk(0, 0, 0), fv.r2o = mk(0, 0, 0), fv.r2d = mk(0, 0, 0), fv.transp = h.transparency;
+            fv.shin = h.shininess, fv.a = 0.0f, fv.r2t = kFltMax, fv.depth = rayDepth, fv.pc = 0, fv.gi = 0, fv.valid2 = 0;
+            RayL refl;
+            refl.o = mk(0, 0, 0), refl.d = mk(0, 0, 0);
+            bool refl_ok = false;
+            if (op == 2) { // the probe of render.cpp:44: its hit distance is the callee's initial ray.t
+                tlim = t;
+                op = 1;
+            } else if (full) {
+                if (!hit) {
+                    stage = GS_RET;
+                } else {
+                    refl_ok = compute_reflection_ray(ray, t, h, refl); // :34
+                    if (fR && !fG) { // the ray of :103-110, needed after the first calls return
+                        if (fT && h.transparency != 1.0f) {
+                            fv.r2o = (0.00001f + t) * ray.d + ray.o;
+                            fv.r2d = ray.d;
+                            fv.r2t = kFltMax;
+                            fv.valid2 = 1;
+                        } else {
+                            fv.r2o = refl.o, fv.r2d = refl.d;
+                            fv.r2t = refl_ok ? kFltMax : 0.0f; // the sentinel Ray{0, 0, 0} of shading.cpp
+                            fv.valid2 = refl_ok ? 1 : 0;
+                        }
+                    }
+                    stage = GS_A;
+                }
+            }
+            // ---- per-lane control: runs until the lane has a new ray to trace or is finished -----
+            // call(): push the frame and make `child` the lane's pending ray
+            RayL child;
+            child.o = mk(0, 0, 0), child.d = mk(0, 0, 0);
+            float child_t = kFltMax;
+            int32_t child_depth = 0;
+            bool child_probe = false;
+            while (stage != GS_DONE) {
+                bool do_call = false;
+                switch (stage) {
+                case GS_A:
+                    if (fT && !fR && !fG) { // :36-49
+                        if (fv.transp == 1.0f || fv.depth <= 0) {
+                            val = fv.Lo;
+                            stage = GS_RET;
+                            break;
+                        }
+                        fv.Lo = fv.Lo * fv.transp;
+                        child.o = (0.00001f + t) * ray.d + ray.o;
+                        child.d = ray.d;
+                        child_t = kFltMax, child_depth = fv.depth - 1, child_probe = true;
+                        fv.pc = 1;
+                        do_call = true;
+                    } else {
+                        stage = GS_B;
+                    }
+                    break;
+                case GS_B:
+                    if (refl_ok && !(fv.depth < 1) && fR) { // :52-54
+                        if (fG && fv.shin != 0.0f) { // :56-71
+                            const V3 w = normalize(refl.d);
+                            V3 tt = w;
+                            float mn = tt.x;
+                            int minIdx = 0;
+                            if (tt.y < mn) {
+                                mn = tt.y;
+                                minIdx = 1;
+                            }
+                            if (tt.z < mn) {
+                                mn = tt.z;
+                                minIdx = 2;
+                            }
+                            if (minIdx == 0)
+                                tt.x = 1.0f;
+                            else if (minIdx == 1)
+                                tt.y = 1.0f;
+                            else
+                                tt.z = 1.0f;
+                            const V3 u = cross(tt, w) / length(cross(tt, w));
+                            fv.w = w, fv.u = u, fv.v = cross(w, u);
+                            fv.a = (1 / fv.shin) * a.alpha_modifier;
+                            fv.gorigin = refl.o;
+                            fv.total = mk(.0f, .0f, .0f);
+                            fv.gi = 0;
+                            stage = GS_BG;
+                        } else { // :97
+                            child = refl, child_t = kFltMax, child_depth = fv.depth - 1, child_probe = false;
+                            fv.pc = 2;
+                            do_call = true;
+                        }
+                    } else {
+                        stage = GS_C;
+                    }
+                    break;
+                case GS_BG: { // the sample loop of :82-95
+                    bool called = false;
+                    while (fv.gi < a.rays_per_reflection) {
+                        const float randOne = rand01(rand31(a.seed, pixel, 61u, 0u, draws & 0x1ffffu, 0u));
+                        const float randTwo = rand01(rand31(a.seed, pixel, 61u, 0u, draws & 0x1ffffu, 1u));
+                        draws++;
+                        fv.gi++;
+                        const float weightU = -fv.a / 2 + randOne * fv.a;
+                        const float weightV = -fv.a / 2 + randTwo * fv.a;
+                        V3 gr = fv.w + weightU * fv.u + weightV * fv.v;
+                        gr = normalize(gr);
+                        if (dot(fv.normal, gr) > 0) {
+                            child.o = fv.gorigin, child.d = gr, child_t = kFltMax;
+                            child_depth = fv.depth - 1 < a.glossy_cap ? fv.depth - 1 : a.glossy_cap;
+                            child_probe = false;
+                            fv.pc = 3;
+                            called = true;
+                            break;
+                        }
+                    }
+                    if (called) {
+                        do_call = true;
+                    } else {
+                        fv.total = fv.total / float(a.rays_per_reflection);
+                        fv.Lo = fv.Lo + fv.total;
+                        stage = GS_C;
+                    }
+                    break;
+                }
+                case GS_C:
+                    if (fR && !fG) { // :101-119
+                        if (fv.valid2 && fv.depth > 0) {
+                            child.o = fv.r2o, child.d = fv.r2d, child_t = fv.r2t, child_depth = fv.depth - 1;
+                            child_probe = false;
+                            fv.pc = 4;
+                            do_call = true;
+                        } else {
+                            stage = GS_C2;
+                        }
+                    } else {
+                        stage = GS_END;
+                    }
+                    break;
+                case GS_C2:
+                    if (fv.transp != 1.0f) { // :121-122, no depth test
+                        child.o = fv.r2o, child.d = fv.r2d, child_t = fv.r2t, child_depth = fv.depth - 1;
+                        child_probe = false;
+                        fv.pc = 5;
+                        do_call = true;
+                    } else {
+                        stage = GS_END;
+                    }
+                    break;
+                case GS_END:
+                    val = fv.Lo;
+                    stage = GS_RET;
+                    break;
+                case GS_RET: // `val` is this invocation's return value
+                    if (sp == 0) {
+                        result = val;
+                        op = 0;
+                        stage = GS_DONE;
+                    } else {
+                        sp--;
+                        gframe_load(my_frames + (size_t)sp * kFrameWords, fv);
+                        stage = GS_RESUME;
+                    }
+                    break;
+                case GS_RESUME:
+                    if (fv.pc == 1) {
+                        fv.Lo = fv.Lo + (1.0f - fv.transp) * val;
+                        stage = GS_END;
+                    } else if (fv.pc == 2) {
+                        fv.Lo = fv.Lo + val;
+                        stage = GS_C;
+                    } else if (fv.pc == 3) {
+                        fv.total = fv.total + val * fv.ks;
+                        stage = GS_BG;
+                    } else if (fv.pc == 4) {
+                        fv.Lo = fv.Lo + val;
+                        stage = GS_C2;
+                    } else {
+                        val = fv.transp * val + (1 - fv.transp) * fv.Lo; // :123 (the intersect of :125-127 has no effect)
+                        stage = GS_RET;
+                    }
+                    break;
+                default:
+                    stage = GS_DONE;
+                    break;
+                }
+                if (do_call) {
+                    if (sp + 1 > a.depth + kExtraFrames) { // recursion guard (oracle: same): the callee returns vec3(0)
+                        val = mk(0.0f, 0.0f, 0.0f);
+                        stage = GS_RESUME;
+                    } else {
+                        gframe_store(my_frames + (size_t)sp * kFrameWords, fv);
+                        sp++;
+                        ray = child, tlim = child_t, rayDepth = child_depth;
+                        op = child_probe ? 2 : 1;
+                        stage = GS_DONE;
+                    }
+                }
+            }
+        }
+        if (active) { // one "level" holding the finished colour: k_fold adds vec3(0) and divides by 1
+            a.state[item] = 1u;
+            float* d = a.direct + 3 * (size_t)item;
+            d[0] = result.x, d[1] = result.y, d[2] = result.z;
+        }
+    }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const LevelArgs a)
 {
@@ -881,6 +1206,25 @@ void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
         hipLaunchKernelGGL(k_trace_level<true>, dim3(grid), dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(k_trace_level<false>, dim3(grid), dim3(kBlock), g_lds_pad, s, a);
+}
+
+uint32_t trace_general_waves(const LevelArgs& a)
+{
+    uint64_t units = a.source == SRC_CAMERA ? camera_waves(a.cam) : ((uint64_t)a.in_count_imm + 63) / 64;
+    const uint64_t cap = 8192; // frame stacks are allocated per wave slot, not per pixel
+    return (uint32_t)(units < cap ? units : cap);
+}
+
+void launch_trace_general(const LevelArgs& a, bool count, hipStream_t s)
+{
+    const uint32_t waves = trace_general_waves(a);
+    if (waves == 0)
+        return;
+    const uint32_t grid = grid_for_waves(waves);
+    if (count)
+        hipLaunchKernelGGL(k_trace_general<true>, dim3(grid), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_trace_general<false>, dim3(grid), dim3(kBlock), 0, s, a);
 }
 
 void launch_fold(const FoldArgs& a, hipStream_t s)

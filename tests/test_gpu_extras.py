@@ -104,3 +104,63 @@ def test_bloom_needs_the_whole_frame(rt, abi, scenes, monkey):
     with pytest.raises(capi.RtError) as e:
         rt.render(bvh, cam, f, p, 32, 32, rows=(0, 8))
     assert e.value.code == abi.RT_ERR_UNSUPPORTED if hasattr(abi, "RT_ERR_UNSUPPORTED") else True
+
+
+# ---- transparency and glossy reflections: recursiveRayTrace's branching variants (render.cpp:36-130) -------
+def _variant(scenes, name):
+    """Fixture scenes with non-opaque, specular materials added (the presets' cornell is fully opaque)."""
+    import copy
+    data = copy.deepcopy(scenes.load_fixture_scene(name))
+    if name == "cornell":
+        for i, m in enumerate(data.meshes):
+            if i >= len(data.meshes) - 3:
+                m.material.transparency = 0.5 if i % 2 else 0.25
+            m.material.ks = (0.4, 0.3, 0.2) if i % 3 else (0.0, 0.0, 0.0)
+            m.material.shininess = 20.0 if i % 2 else 0.0
+    if name == "spheres":
+        for i, s in enumerate(data.spheres):
+            s.material.transparency = 0.6 if i != 1 else 1.0
+            s.material.ks = (0.5, 0.5, 0.5)
+    return data
+
+
+RECURSION_CASES = [
+    ("cornell", dict(enableTransparency=1), dict(depth=4)),                         # :36-49 chain with the probe
+    ("spheres", dict(enableTransparency=1), dict(depth=3)),                         # strict `<` of spheres after the probe
+    ("cornell", dict(enableRecursive=1), dict(depth=3)),                            # :121-129 without the extra
+    ("cornell", dict(enableRecursive=1, enableTransparency=1), dict(depth=3)),      # pass-through rays, shadow transparency
+    ("spheres", dict(enableRecursive=1, enableTransparency=1), dict(depth=2)),
+    ("monkey", dict(enableRecursive=1, enableGlossyReflection=1), dict(depth=3, rays_per_reflection=3)),
+    ("cornell", dict(enableRecursive=1, enableGlossyReflection=1), dict(depth=4, rays_per_reflection=2, alpha_modifier=1.5)),
+    ("cube", dict(enableRecursive=1, enableSoftShadow=1), dict(depth=5, segment_n=4)),  # d != 1 in cube.mtl, segment light
+]
+
+
+@pytest.mark.parametrize("scene,flags,params", RECURSION_CASES)
+def test_recursion_variants_match_oracle(rt, oracle, abi, scenes, scene, flags, params):
+    data = _variant(scenes, scene)
+    f = abi.Features.make(enableShading=1, enableHardShadow=1, enableAccelStructure=1, **flags)
+    p = abi.RenderParams.make(**params)
+    W, H = 64, 48
+    args = scenes.default_camera_args(W, H)
+    bvh = rt.bvh(rt.scene(data), f)
+    ob = oracle.build(data, f)
+    rgb = rt.render(bvh, rt.camera(*args), f, p, W, H)
+    orgb, _, _, _ = oracle.render(ob, oracle.camera(*args), f, p, W, H)
+    assert np.isfinite(orgb).any() and (orgb[np.isfinite(orgb)] != 0).any(), "test scene renders black"
+    assert_colors_close(rgb, orgb)
+
+
+def test_recursion_variants_trace_batch(rt, oracle, abi, scenes):
+    """getFinalColor on a ray batch goes through the same state machine."""
+    from test_gpu_parity import make_rays
+    data = _variant(scenes, "cornell")
+    f = abi.Features.make(enableShading=1, enableHardShadow=1, enableAccelStructure=1, enableRecursive=1,
+                          enableTransparency=1)
+    p = abi.RenderParams.make(depth=3)
+    bvh = rt.bvh(rt.scene(data), f)
+    ob = oracle.build(data, f)
+    rays = make_rays(abi, np.random.default_rng(5), 777, scale=2.0)
+    got = rt.trace_batch(bvh, rays, f, p)
+    want, _ = oracle.trace_batch(ob, rays, f, p)
+    assert_colors_close(got, want)

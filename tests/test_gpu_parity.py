@@ -314,19 +314,18 @@ def test_slab_division_is_the_ieee_quotient(rt):
             assert fast > (1 << 27), "the fast path must be the one exercised"
 
 
-def test_unsupported_features_fail_loudly(rt, abi, scenes, built):
+def test_bad_parameters_fail_loudly(rt, abi, scenes, built):
+    """Every Features flag the reference's render path reads is implemented (tests/test_gpu_extras.py
+    for the extras); what is left to refuse are parameters outside their ranges."""
     capi = __import__("importlib").import_module("computer-graphics-engine_amd.capi")
     f_ok = abi.Features.make(enableShading=1, enableAccelStructure=1)
     data, sc, bvh, ob = built("cornell", f_ok)
     cam = rt.camera(*scenes.default_camera_args(32, 32))
-    p = abi.RenderParams.make()
-    for flag in ("enableGlossyReflection", "enableTransparency"):  # the other extras: tests/test_gpu_extras.py
-        f = abi.Features.make(enableShading=1, enableAccelStructure=1, **{flag: 1})
+    for feat, bad in ((dict(), dict(depth=-1)), (dict(), dict(depth=62)),
+                      (dict(enableMultipleRaysPerPixel=1), dict(rays_per_pixel_side=0)),
+                      (dict(enableDepthOfField=1), dict(samples_dof=0)),
+                      (dict(enableRecursive=1, enableGlossyReflection=1), dict(rays_per_reflection=0))):
+        f = abi.Features.make(enableShading=1, enableAccelStructure=1, **feat)
         with pytest.raises(capi.RtError) as e:
-            rt.render(bvh, cam, f, p, 32, 32)
-        assert e.value.code == abi.RT_ERR_UNSUPPORTED
-    # cube.mtl has d != 1: recursive takes render.cpp:122-130 (out of scope) → refused
-    f_rec = abi.Features.make(enableShading=1, enableRecursive=1, enableAccelStructure=1)
-    d2, sc2, bvh2, _ = built("cube", f_rec)
-    with pytest.raises(capi.RtError):
-        rt.render(bvh2, cam, f_rec, p, 32, 32)
+            rt.render(bvh, cam, f, abi.RenderParams.make(**bad), 32, 32)
+        assert e.value.code == abi.RT_ERR_INVALID
