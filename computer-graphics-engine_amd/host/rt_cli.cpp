@@ -7,9 +7,19 @@
 //          [--size W H] [--depth N] [--features shading,recursive,hard_shadow,soft_shadow,
 //            normal_interp,texture,bvh,sah,bilinear] [--camera FOV DIST RX RY]... [--out PREFIX]
 //
+//   rt_cli CONFIG.toml            the reference's own configuration file (src/config.cpp:193-374:
+//          window_size, data_path, scene, output_dir, [features], [features.extra], [[cameras]],
+//          [[lights]]); images are named {scene}_{start time}_cam_{i}.bmp in output_dir like
+//          src/main.cpp:518-521. Keys the reference does not read but its Features struct has
+//          (enable_soft_shadow, extra.enable_bvh_sah_binning, extra.enable_transparency) are accepted too.
+//
 // Several --camera options render several images (the reference spawns one thread per
 // camera; here the frames go to the GPU one after the other).
 #include <chrono>
+#include <ctime>
+#include <fstream>
+#include <sstream>
+#include <sys/stat.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +28,7 @@
 #include <vector>
 
 #include "../../include/rt_whitted.h"
+#include "mini_toml.hpp"
 
 extern "C" {
 typedef struct rt_loaded_scene rt_loaded_scene;
@@ -38,13 +49,19 @@ int main(int argc, char** argv)
     memset(&f, 0, sizeof(f));
     f.enableShading = f.enableAccelStructure = 1;
     struct Cam {
-        float fov, dist, rx, ry;
+        float fov, dist, rx, ry, rz = 0.0f;
+        float look[3] = { 0.0f, 0.0f, 0.0f };
     };
     std::vector<Cam> cams;
+    std::vector<rt_light_desc> cfg_lights; // [[lights]] of a config file (scene files only, like loadSceneFromFile)
+    std::string config_path, scene_label;
+    bool have_config = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](int n) { return i + n < argc; };
-        if (a == "--data" && need(1)) data = argv[++i];
+        if (a == "--config" && need(1)) config_path = argv[++i];
+        else if (i == 1 && a.size() > 5 && a.substr(a.size() - 5) == ".toml") config_path = a; // src/main.cpp:48-49
+        else if (a == "--data" && need(1)) data = argv[++i];
         else if (a == "--scene" && need(1)) scene = argv[++i];
         else if (a == "--obj" && need(1)) obj = argv[++i];
         else if (a == "--normalize") normalize = true;
@@ -76,7 +93,145 @@ int main(int argc, char** argv)
             return die("unknown or incomplete option", a.c_str());
         }
     }
-    if (cams.empty())
+    if (!config_path.empty()) { // ≙ readConfigFile, src/config.cpp:193-374
+        std::ifstream in(config_path);
+        if (!in)
+            return die("cannot open the config file", config_path.c_str());
+        std::stringstream ss;
+        ss << in.rdbuf();
+        const std::string text = ss.str();
+        mini_toml::Value cfg;
+        const std::string perr = mini_toml::Parser(text).parse(cfg);
+        if (!perr.empty())
+            return die("config file", perr.c_str());
+        have_config = true;
+        auto vec = [](const mini_toml::Value* v, size_t n, float* out) {
+            if (!v || v->kind != mini_toml::Value::ARRAY || v->a.size() < n)
+                return false;
+            for (size_t k = 0; k < n; k++) {
+                if (!v->a[k].is_number())
+                    return false;
+                out[k] = (float)v->a[k].number();
+            }
+            return true;
+        };
+        float ws[2];
+        if (vec(cfg.get("window_size"), 2, ws))
+            W = (int)ws[0], H = (int)ws[1];
+        const std::string dp = cfg.string_or("data_path", "default");
+        if (dp != "default")
+            data = dp;
+        if (const mini_toml::Value* sv = cfg.get("scene")) {
+            static const char* serial[] = { "single_triangle", "cube", "cube_textured", "cornell_box",
+                "cornell_box_parallelogram_light", "monkey", "teapot", "dragon", "spheres", "custom" };
+            static const char* cli[] = { "single_triangle", "cube", "cube_textured", "cornell", "cornell_parallelogram",
+                "monkey", "teapot", "dragon", "spheres", "custom" };
+            if (sv->kind == mini_toml::Value::INT && sv->i >= 0 && sv->i < 10) {
+                scene = cli[sv->i], scene_label = serial[sv->i];
+            } else if (sv->kind == mini_toml::Value::STRING) {
+                std::string low, flat;
+                for (char ch : sv->s)
+                    low += (char)std::tolower((unsigned char)ch);
+                for (char ch : low)
+                    if (ch != '_' && ch != '-')
+                        flat += ch;
+                for (int t = 0; t < 10 && scene.empty(); t++) { // deserialize(), src/config.cpp:403-430
+                    std::string f2;
+                    for (const char* q = serial[t]; *q; q++)
+                        if (*q != '_')
+                            f2 += *q;
+                    if (flat == f2)
+                        scene = cli[t], scene_label = serial[t];
+                }
+                if (scene.empty()) { // a scene file below data_path
+                    obj = data + "/" + sv->s;
+                    const size_t slash = sv->s.find_last_of('/'), dot = sv->s.find_last_of('.');
+                    const size_t b0 = slash == std::string::npos ? 0 : slash + 1;
+                    scene_label = sv->s.substr(b0, dot == std::string::npos || dot < b0 ? std::string::npos : dot - b0);
+                }
+            }
+        }
+        std::string od = cfg.string_or("output_dir", "");
+        if (!od.empty() && od[0] == '~' && std::getenv("HOME"))
+            od.replace(0, 1, std::getenv("HOME"));
+        if (od.rfind("$HOME", 0) == 0 && std::getenv("HOME"))
+            od.replace(0, 5, std::getenv("HOME"));
+        if (!od.empty()) {
+            std::string partial;
+            for (size_t k = 0; k <= od.size(); k++) // create_directories
+                if (k == od.size() || od[k] == '/') {
+                    partial = od.substr(0, k);
+                    if (!partial.empty())
+                        mkdir(partial.c_str(), 0777);
+                }
+        }
+        char stamp[64];
+        const std::time_t now = std::time(nullptr);
+        std::strftime(stamp, sizeof(stamp), "%Y-%m-%d-%H:%M:%S", std::localtime(&now));
+        out = (od.empty() ? std::string(".") : od) + "/" + scene_label + "_" + stamp;
+        memset(&f, 0, sizeof(f));
+        if (const mini_toml::Value* ft = cfg.get("features")) {
+            f.enableShading = ft->boolean_or("enable_shading", false);
+            f.enableRecursive = ft->boolean_or("enable_recursive", false);
+            f.enableHardShadow = ft->boolean_or("enable_hard_shadow", false);
+            f.enableSoftShadow = ft->boolean_or("enable_soft_shadow", false);
+            f.enableNormalInterp = ft->boolean_or("enable_normal_interp", false);
+            f.enableTextureMapping = ft->boolean_or("enable_texture_mapping", false);
+            f.enableAccelStructure = ft->boolean_or("enable_accel_structure", false);
+            if (const mini_toml::Value* ex = ft->get("extra")) {
+                f.enableBloomEffect = ex->boolean_or("enable_bloom_effect", false);
+                f.enableMultipleRaysPerPixel = ex->boolean_or("enable_multiple_rays_per_pixel", false);
+                f.enableMotionBlur = ex->boolean_or("enable_motion_blur", false);
+                f.enableDepthOfField = ex->boolean_or("enable_depth_of_field", false);
+                f.enableGlossyReflection = ex->boolean_or("enable_glossy_reflection", false);
+                f.enableEnvironmentMapping = ex->boolean_or("enable_environment_mapping", false);
+                f.enableBilinearTextureFiltering = ex->boolean_or("enable_bilinear_texture_filtering", false);
+                f.enableMipmapTextureFiltering = ex->boolean_or("enable_mipmap_texture_filtering", false);
+                f.enableBvhSahBinning = ex->boolean_or("enable_bvh_sah_binning", false);
+                f.enableTransparency = ex->boolean_or("enable_transparency", false);
+            }
+        }
+        if (const mini_toml::Value* cs = cfg.get("cameras"))
+            for (const mini_toml::Value& c : cs->a) {
+                Cam cam { (float)c.number_or("field_of_view", 50.0), (float)c.number_or("distance_from_look_at", 3.0), 20.0f, 20.0f };
+                vec(c.get("look_at"), 3, cam.look);
+                float rot[3];
+                if (vec(c.get("rotation"), 3, rot))
+                    cam.rx = rot[0], cam.ry = rot[1], cam.rz = rot[2];
+                cams.push_back(cam);
+            }
+        if (const mini_toml::Value* ls = cfg.get("lights")) {
+            for (const mini_toml::Value& l : ls->a) {
+                rt_light_desc ld;
+                memset(&ld, 0, sizeof(ld));
+                const std::string type = l.string_or("type", "none");
+                auto sub = [&](const char* key, size_t idx) -> const mini_toml::Value* {
+                    const mini_toml::Value* arr = l.get(key);
+                    return arr && arr->kind == mini_toml::Value::ARRAY && idx < arr->a.size() ? &arr->a[idx] : nullptr;
+                };
+                if (type == "point") { // members in declaration order, src/common.h:37-52
+                    ld.kind = RT_LIGHT_POINT;
+                    vec(l.get("position"), 3, ld.v[0]), vec(l.get("color"), 3, ld.v[1]);
+                } else if (type == "segment") {
+                    ld.kind = RT_LIGHT_SEGMENT;
+                    vec(sub("endpoints", 0), 3, ld.v[0]), vec(sub("endpoints", 1), 3, ld.v[1]);
+                    vec(sub("colors", 0), 3, ld.v[2]), vec(sub("colors", 1), 3, ld.v[3]);
+                } else if (type == "parallelogram") {
+                    ld.kind = RT_LIGHT_PARALLELOGRAM;
+                    vec(l.get("corner"), 3, ld.v[0]), vec(sub("edges", 0), 3, ld.v[1]), vec(sub("edges", 1), 3, ld.v[2]);
+                    for (size_t k = 0; k < 4; k++)
+                        vec(sub("colors", k), 3, ld.v[3 + k]);
+                } else {
+                    std::fprintf(stderr, "Unknown light type: %s -- Skip\n", type.c_str());
+                    continue;
+                }
+                cfg_lights.push_back(ld);
+            }
+        } else {
+            std::fprintf(stderr, "WARN: No lights found in config file.\n");
+        }
+    }
+    if (cams.empty() && !have_config)
         cams.push_back(Cam { 50.0f, 3.0f, 20.0f, 20.0f }); // CameraConfig defaults, src/config.h:16-21
 
     static const char* names[] = { "single_triangle", "cube", "cube_textured", "cornell", "cornell_parallelogram",
@@ -88,7 +243,10 @@ int main(int argc, char** argv)
         memset(&light, 0, sizeof(light));
         light.kind = RT_LIGHT_POINT;
         light.v[0][0] = -1, light.v[0][1] = 1, light.v[0][2] = -1, light.v[1][0] = light.v[1][1] = light.v[1][2] = 1;
-        rc = rt_load_obj(obj.c_str(), normalize ? 1 : 0, &light, 1, &loaded);
+        if (have_config) // loadSceneFromFile(path, config.lights), src/scene.cpp:94-103 (no normalisation)
+            rc = rt_load_obj(obj.c_str(), 0, cfg_lights.empty() ? nullptr : cfg_lights.data(), (uint32_t)cfg_lights.size(), &loaded);
+        else
+            rc = rt_load_obj(obj.c_str(), normalize ? 1 : 0, &light, 1, &loaded);
     } else {
         int type = -1;
         for (int t = 0; t < 10; t++)
@@ -118,8 +276,8 @@ int main(int argc, char** argv)
     const auto r0 = clock::now();
     for (size_t i = 0; i < cams.size(); i++) {
         rt_camera cam;
-        const float look[3] = { 0, 0, 0 }, rot[3] = { cams[i].rx * deg, cams[i].ry * deg, 0.0f };
-        rt_camera_from_trackball(cams[i].fov * deg, float(W) / float(H), look, cams[i].dist, rot, &cam);
+        const float rot[3] = { cams[i].rx * deg, cams[i].ry * deg, cams[i].rz * deg }; // glm::radians(rotation)
+        rt_camera_from_trackball(cams[i].fov * deg, float(W) / float(H), cams[i].look, cams[i].dist, rot, &cam);
         if (rt_render(bvh, &cam, &f, &params, W, H, 0, H, frame.data(), nullptr) != RT_OK)
             return die("rt_render", rt_last_error());
         const std::string path = out + "_cam_" + std::to_string(i) + ".bmp";

@@ -111,3 +111,79 @@ def test_cli_renders_an_obj_to_bmp(rt, abi, scenes, tmp_path):
         assert (frame > 0).any()
         rt.write_bmp(tmp_path / "want.bmp", frame)
         assert (tmp_path / f"img_cam_{i}.bmp").read_bytes() == (tmp_path / "want.bmp").read_bytes()
+
+
+@pytest.mark.gpu
+def test_cli_reads_the_reference_config_format(rt, abi, scenes, tmp_path):
+    """`rt_cli config.toml` ≙ readConfigFile + the command-line mode (src/config.cpp:193-374,
+    src/main.cpp:478-535): a scene file below data_path, [[lights]], [[cameras]], [features] and
+    [features.extra]; images named {scene}_{time}_cam_{i}.bmp in output_dir."""
+    import glob
+    subprocess.run(["make", "-C", str(HOST)], check=True, capture_output=True)
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.8 0.3 0.2\nKs 0.5 0.5 0.5\nNs 20\n")
+    (tmp_path / "pyramid.obj").write_text("mtllib m.mtl\nusemtl a\nv -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nv 0 0 -1.5\n"
+                                          "f 4 3 2 1\nf 2 1 5\nf 3 2 5\nf 4 3 5\nf 1 4 5\n")
+    W, H = 80, 56
+    (tmp_path / "job.toml").write_text(f'''
+# comment line
+command_line_rendering = true
+window_size = [{W}, {H}]          # trailing comment
+data_path = "{tmp_path}"
+scene = "pyramid.obj"
+output_dir = "{tmp_path}/out/nested"
+
+[features]
+enable_shading = true
+enable_recursive = true
+enable_hard_shadow = true
+enable_accel_structure = true
+enable_normal_interp = false
+
+[features.extra]
+enable_multiple_rays_per_pixel = true
+enable_bloom_effect = true
+
+[[cameras]]
+field_of_view = 50.0
+distance_from_look_at = 3.0
+look_at = [0.0, 0.1, 0.0]
+rotation = [20.0, 20.0, 0.0]
+
+[[cameras]]
+field_of_view = 40
+distance_from_look_at = 4
+rotation = [-10.0, 35.0, 5.0]
+
+[[lights]]
+type = "point"
+position = [-1.0, 1.0, -1.0]
+color = [1.0, 0.9, 0.8]
+
+[[lights]]
+type = "segment"
+endpoints = [[1.0, 1.0, -1.0], [1.5, 1.0, -1.0]]
+colors = [[0.2, 0.2, 0.2], [0.1, 0.1, 0.3]]
+''')
+    r = subprocess.run([str(HOST / "rt_cli"), str(tmp_path / "job.toml")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "2 images rendered" in r.stdout
+    lights = [abi.LightData.point((-1, 1, -1), (1, 0.9, 0.8)),
+              abi.LightData.segment((1, 1, -1), (1.5, 1, -1), (0.2, 0.2, 0.2), (0.1, 0.1, 0.3))]
+    scene = rt.load_obj(tmp_path / "pyramid.obj", lights=lights)
+    f = abi.Features.make(enableShading=1, enableHardShadow=1, enableRecursive=1, enableAccelStructure=1,
+                          enableMultipleRaysPerPixel=1, enableBloomEffect=1)
+    bvh = rt.bvh(rt.scene(scene), f)
+    cams = [(50, 3, (0, 0.1, 0), (20, 20, 0)), (40, 4, (0, 0, 0), (-10, 35, 5))]
+    for i, (fov, dist, look, rot) in enumerate(cams):
+        cam = rt.camera(float(scenes.radians(fov)), float(np.float32(W) / np.float32(H)), look, dist,
+                        tuple(float(scenes.radians(a)) for a in rot))
+        frame = rt.render(bvh, cam, f, abi.RenderParams.make(depth=5), W, H)
+        assert (frame > 0).any()
+        rt.write_bmp(tmp_path / "want.bmp", frame)
+        got = glob.glob(str(tmp_path / "out" / "nested" / f"pyramid_*_cam_{i}.bmp"))
+        assert len(got) == 1, got
+        assert open(got[0], "rb").read() == (tmp_path / "want.bmp").read_bytes()
+    # a syntax error is reported with its line, nothing is rendered
+    (tmp_path / "bad.toml").write_text("window_size = [10, 10\nscene = 3\n")
+    r = subprocess.run([str(HOST / "rt_cli"), str(tmp_path / "bad.toml")], capture_output=True, text=True)
+    assert r.returncode != 0 and "line" in r.stderr
