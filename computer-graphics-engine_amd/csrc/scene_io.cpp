@@ -16,6 +16,7 @@
 #include <zlib.h>
 
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -450,8 +451,110 @@ int load_obj(rt_loaded_scene& sc, const std::string& file, bool center_and_norma
                     shape.indices.push_back(i);
                 shape.material_ids.push_back(material);
             } else {
-                fail_msg = file + ": polygon with " + std::to_string(np)
-                    + " vertices (tinyobjloader's ear clipping is not restated)";
+                // tinyobjloader's built-in ear clipping (tiny_obj_loader.h:1540-1819), np > 4:
+                // pick the two axes of the first non-degenerate corner, then clip ears.
+                size_t axes[2] = { 1, 2 };
+                for (size_t k = 0; k < np; ++k) {
+                    const Idx &i0 = face[(k + 0) % np], &i1 = face[(k + 1) % np], &i2 = face[(k + 2) % np];
+                    const size_t vi0 = (size_t)i0.v, vi1 = (size_t)i1.v, vi2 = (size_t)i2.v;
+                    if (((3 * vi0 + 2) >= v.size()) || ((3 * vi1 + 2) >= v.size()) || ((3 * vi2 + 2) >= v.size()))
+                        continue;
+                    const float v0x = v[vi0 * 3 + 0], v0y = v[vi0 * 3 + 1], v0z = v[vi0 * 3 + 2];
+                    const float v1x = v[vi1 * 3 + 0], v1y = v[vi1 * 3 + 1], v1z = v[vi1 * 3 + 2];
+                    const float v2x = v[vi2 * 3 + 0], v2y = v[vi2 * 3 + 1], v2z = v[vi2 * 3 + 2];
+                    const float e0x = v1x - v0x, e0y = v1y - v0y, e0z = v1z - v0z;
+                    const float e1x = v2x - v1x, e1y = v2y - v1y, e1z = v2z - v1z;
+                    const float cx = std::fabs(e0y * e1z - e0z * e1y);
+                    const float cy = std::fabs(e0z * e1x - e0x * e1z);
+                    const float cz = std::fabs(e0x * e1y - e0y * e1x);
+                    const float epsilon = std::numeric_limits<float>::epsilon();
+                    if (cx > epsilon || cy > epsilon || cz > epsilon) {
+                        if (cx > cy && cx > cz) {
+                        } else {
+                            axes[0] = 0;
+                            if (cz > cx && cz > cy)
+                                axes[1] = 1;
+                        }
+                        break;
+                    }
+                }
+                auto pnpoly = [](int nvert, const float* vertx, const float* verty, float testx, float testy) {
+                    int i, j, c = 0;
+                    for (i = 0, j = nvert - 1; i < nvert; j = i++) {
+                        if (((verty[i] > testy) != (verty[j] > testy))
+                            && (testx < (vertx[j] - vertx[i]) * (testy - verty[i]) / (verty[j] - verty[i]) + vertx[i]))
+                            c = !c;
+                    }
+                    return c;
+                };
+                std::vector<Idx> remaining = face;
+                size_t guess_vert = 0;
+                Idx ind[3];
+                float vx[3], vy[3];
+                size_t remainingIterations = face.size();
+                size_t previousRemainingVertices = remaining.size();
+                while (remaining.size() > 3 && remainingIterations > 0) {
+                    const size_t npolys = remaining.size();
+                    if (guess_vert >= npolys)
+                        guess_vert -= npolys;
+                    if (previousRemainingVertices != npolys) {
+                        previousRemainingVertices = npolys;
+                        remainingIterations = npolys;
+                    } else {
+                        remainingIterations--;
+                    }
+                    for (size_t k = 0; k < 3; k++) {
+                        ind[k] = remaining[(guess_vert + k) % npolys];
+                        const size_t vi = (size_t)ind[k].v;
+                        if (((vi * 3 + axes[0]) >= v.size()) || ((vi * 3 + axes[1]) >= v.size())) {
+                            vx[k] = 0.0f;
+                            vy[k] = 0.0f;
+                        } else {
+                            vx[k] = v[vi * 3 + axes[0]];
+                            vy[k] = v[vi * 3 + axes[1]];
+                        }
+                    }
+                    const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0];
+                    const float e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+                    const float cross = e0x * e1y - e0y * e1x;
+                    const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+                    if (cross * area < 0.0f) { // an internal angle
+                        guess_vert += 1;
+                        continue;
+                    }
+                    bool overlap = false;
+                    for (size_t otherVert = 3; otherVert < npolys; ++otherVert) {
+                        const size_t idx = (guess_vert + otherVert) % npolys;
+                        if (idx >= remaining.size())
+                            continue;
+                        const size_t ovi = (size_t)remaining[idx].v;
+                        if (((ovi * 3 + axes[0]) >= v.size()) || ((ovi * 3 + axes[1]) >= v.size()))
+                            continue;
+                        const float tx = v[ovi * 3 + axes[0]], ty = v[ovi * 3 + axes[1]];
+                        if (pnpoly(3, vx, vy, tx, ty)) {
+                            overlap = true;
+                            break;
+                        }
+                    }
+                    if (overlap) {
+                        guess_vert += 1;
+                        continue;
+                    }
+                    for (int k = 0; k < 3; k++) // this triangle is an ear
+                        shape.indices.push_back(ind[k]);
+                    shape.material_ids.push_back(material);
+                    size_t removed_vert_index = (guess_vert + 1) % npolys; // remove v1 from the list
+                    while (removed_vert_index + 1 < npolys) {
+                        remaining[removed_vert_index] = remaining[removed_vert_index + 1];
+                        removed_vert_index += 1;
+                    }
+                    remaining.pop_back();
+                }
+                if (remaining.size() == 3) {
+                    for (int k = 0; k < 3; k++)
+                        shape.indices.push_back(remaining[k]);
+                    shape.material_ids.push_back(material);
+                }
             }
         }
     };

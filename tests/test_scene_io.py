@@ -167,8 +167,7 @@ def test_loader_errors_are_loud(lib, tmp_path):
     with pytest.raises(capi.RtError):
         lib.load_obj(tmp_path / "missing.obj")                     # mesh.cpp:54-57 throws
     (tmp_path / "p.obj").write_text("v 0 0 0\nv 1 0 0\nv 2 1 0\nv 1 2 0\nv 0 1 0\nf 1 2 3 4 5\n")
-    with pytest.raises(capi.RtError):
-        lib.load_obj(tmp_path / "p.obj")                           # pentagon: ear clipping not restated
+    assert len(lib.load_obj(tmp_path / "p.obj").meshes[0].triangles) == 3   # pentagon: ear clipping (pinned below)
     with pytest.raises(capi.RtError):
         lib.load_preset(7, str(tmp_path))                          # Dragon: dragon.obj is absent upstream too
 
@@ -217,3 +216,25 @@ def test_bmp_export_layout(lib, tmp_path):
     assert px[0, 0].tolist() == [63, 127, 255, 255]                              # B G R A, truncation
     assert px[0, 1].tolist() == [0, 0, 255, 255]                                 # NaN → 0, clamps
     assert px[2, 4].tolist() == [1, 1, 254, 255]
+
+
+def test_polygons_with_more_than_four_vertices_equal_the_reference_loader(lib, tmp_path):
+    """tinyobjloader's built-in ear clipping (tiny_obj_loader.h:1540-1819): convex / concave
+    5-, 6-, 8- and 10-gons in differently oriented planes. tests/golden/polygons.npz holds the
+    OBJ text and what the REFERENCE loader chain produced for it (oracle/make_golden_polygons.py,
+    run in the container against oracle/_ref) — compared bit for bit."""
+    from conftest import GOLDEN
+    with np.load(GOLDEN / "polygons.npz", allow_pickle=False) as z:
+        (tmp_path / "custom.obj").write_bytes(z["obj"].tobytes())
+        (tmp_path / "custom.mtl").write_bytes(z["mtl"].tobytes())
+        got = lib.load_preset(9, str(tmp_path))  # SceneType::Custom → loadMesh(dataDir / "custom.obj")
+        assert len(got.meshes) == int(z["n_meshes"])
+        for i, m in enumerate(got.meshes):
+            assert np.array_equal(m.triangles, z[f"m{i}_triangles"])
+            assert np.array_equal(bits(m.positions), bits(z[f"m{i}_positions"]))
+            assert np.array_equal(bits(m.normals), bits(z[f"m{i}_normals"]))
+            assert np.array_equal(bits(m.texcoords), bits(z[f"m{i}_texcoords"]))
+            want_mat = z[f"m{i}_material"]
+            got_mat = np.float32(list(m.material.kd) + list(m.material.ks) + [m.material.shininess, m.material.transparency])
+            assert np.array_equal(bits(got_mat), bits(want_mat))
+        assert sum(len(m.triangles) for m in got.meshes) == 3 + 4 + 6 + 6 + 8 + 2 + 1
