@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 }, g_fused_from { 0 };
+std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 }, g_fused_from { 0 }, g_merge_next { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -346,6 +346,7 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     // queue between them), level k's launch then runs all deeper levels inside its waves
     const int32_t fused_from = fused ? std::min(g_fused_from.load(), n_levels - 1) : n_levels;
     a.prio_levels = g_prio.load() ? 1u : 0u;
+    a.merge_next = g_merge_next.load() ? 1u : 0u;
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
     if (source == rt::SRC_CAMERA) {
@@ -514,6 +515,10 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "prio") == 0) { // 1: deeper recursion levels get a higher wave priority (default)
         g_prio.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "merge_next") == 0) { // 1: shadow rays of level k share a traversal with the reflection rays of level k + 1
+        g_merge_next.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "fused_from") == 0) { // first recursion level that runs fused (0 = one launch per frame)

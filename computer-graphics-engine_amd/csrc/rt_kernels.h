@@ -68,6 +68,7 @@ struct LevelArgs {
     size_t level_stride;      // floats between the `direct` planes of consecutive levels
     ShareArgs share;
     uint32_t prio_levels;     // 1: s_setprio by recursion level (deeper = higher)
+    uint32_t merge_next;      // 1: trace a level's first shadow rays together with the next level's reflection rays
     RaySoA out;
     uint32_t* out_count;
     float* direct;   // this level's direct-light colours, n_items * 3

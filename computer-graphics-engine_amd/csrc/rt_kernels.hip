@@ -177,21 +177,30 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
 // bvh.intersect's HitInfo (bvh.cpp:365-426) and computeLightContribution (light.cpp:108-165) for the
 // lanes with `hit`: returns Lo (the albedo when shading is off); ALL lanes of the wave must call
 // (the shadow rays are traced by the whole wave).
-template <bool COUNT>
+// GENERAL: also compiles the shadow query of enableTransparency (closest blocker's transparency) —
+// only k_trace_general needs it, the plain kernel stays one traversal instantiation smaller.
+// The next level's closest-hit query, traced TOGETHER with this level's first shadow query
+// (traverse<Q_MIXED>): pixel lanes (all < 32) carry their reflection ray in their own ray slot,
+// lane p + 32 carries pixel p's shadow ray. One traversal with twice the rays instead of two:
+// better lane use in the node phase and half as many serial traversals per path tree.
+struct MergeNext {
+    bool enabled = false; // pixel lanes are all < 32 and the launch runs fused
+    bool done = false;    // the merged traversal ran: pos / t hold the next level's closest hit
+    bool spawn = false;   // this lane has a reflection ray
+    RayL refl;
+    int32_t pos = -1;
+    float t = kFltMax;
+};
+
+template <bool COUNT, bool GENERAL>
 RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int32_t pos, int32_t level, uint32_t pixel,
-    HitL& h, LaneCounters& lc, RayCounts& rc, WaveLds& wl)
+    const HitL& h, LaneCounters& lc, RayCounts& rc, WaveLds& wl, MergeNext* mg)
 {
     const SceneView& sv = a.sv;
     const uint32_t flags = a.flags;
     const bool use_bvh = (flags & F_ACCEL) != 0;
     const bool prune = (flags & F_NO_PRUNE) == 0;
-    h.normal = mk(0, 0, 1), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
-    h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
-    if (hit)
-        resolve_hit(sv, flags, ray, t, pos, h);
-    if (COUNT && hit)
-        rc.hits = 1;
-
+    (void)pos;
     // ---- computeLightContribution (light.cpp:108-165) ---------------------------
     V3 Lo = h.kd; // !enableShading: the albedo (light.cpp:161-164)
     if (flags & F_SHADING) {
@@ -243,12 +252,34 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                     int32_t spos;
                     if (COUNT && hit)
                         rc.shadow++;
-                    if (!(flags & F_TRANSPARENCY)) {
-                        traverse<true, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
+                    if (!GENERAL && mg && mg->enabled && !mg->done) {
+                        const uint32_t lane = lane_id();
+                        const bool upper = lane >= 32u;
+                        const int src = (int)(lane & 31u);
+                        // lane p + 32 takes pixel p's shadow ray
+                        RayL q;
+                        q.o = mk(__shfl(sray.o.x, src, 64), __shfl(sray.o.y, src, 64), __shfl(sray.o.z, src, 64));
+                        q.d = mk(__shfl(sray.d.x, src, 64), __shfl(sray.d.y, src, 64), __shfl(sray.d.z, src, 64));
+                        const bool hit_lo = __shfl((int)hit, src, 64) != 0;
+                        bool act = hit_lo;
+                        float tq = 1.0f;
+                        if (!upper) {
+                            q = mg->refl;
+                            act = mg->spawn;
+                            tq = kFltMax;
+                        }
+                        int32_t pq;
+                        traverse<Q_MIXED, COUNT>(sv, use_bvh, prune, act, q, tq, pq, lc, wl);
+                        mg->pos = pq, mg->t = tq, mg->done = true;
+                        spos = __shfl(pq, (int)(lane | 32u), 64);
+                        if (spos >= 0)
+                            visibility = 0.0f;
+                    } else if (!GENERAL || !(flags & F_TRANSPARENCY)) {
+                        traverse<Q_ANY, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
                         if (spos >= 0)
                             visibility = 0.0f;
                     } else { // light.cpp:66-69: the CLOSEST blocker's material.transparency
-                        traverse<false, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
+                        traverse<Q_CLOSEST, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
                         if (spos >= 0)
                             visibility = hit_transparency(sv, flags, spos);
                     }
@@ -392,12 +423,16 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
                 rc.closest = 1;
             float t = tlim;
             int32_t pos;
-            traverse<false, COUNT>(sv, use_bvh, prune, want, ray, t, pos, lc, wl);
+            traverse<Q_CLOSEST, COUNT>(sv, use_bvh, prune, want, ray, t, pos, lc, wl);
             const bool full = op == 1;
             const bool hit = full && pos >= 0;
             const int32_t level = a.depth - rayDepth;
             HitL h;
-            const V3 Lo0 = shade_hit<COUNT>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl);
+            h.normal = mk(0, 0, 1), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
+            h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
+            if (hit)
+                resolve_hit(sv, flags, ray, t, pos, h);
+            const V3 Lo0 = shade_hit<COUNT, true>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, nullptr);
             if (COUNT && hit)
                 rc.hits = 1;
             if (COUNT)
@@ -706,6 +741,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
 
     const int32_t first_level = a.level;
     int32_t level = first_level;
+    MergeNext mg;
+    mg.refl.o = mk(0, 0, 0), mg.refl.d = mk(0, 0, 0);
+    // merged traversals need every pixel lane below 32 (tiles of up to 32 pixels) and a fused launch
+    mg.enabled = a.fused != 0u && a.merge_next != 0u && (ballot(active) >> 32) == 0ull;
     for (;;) { // work units of this wave: its own tile, then (Helpers) packets of other waves
     if (ballot(active) != 0)
     for (;; level++) {
@@ -721,9 +760,16 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         else
             __builtin_amdgcn_s_setprio(3);
     }
-    // ---- closest hit (bvh.intersect, render.cpp:31) -----------------------------
+    // ---- closest hit (bvh.intersect, render.cpp:31) — unless the previous level's merged
+    //      traversal (MergeNext) already found it
     int32_t pos;
-    traverse<false, COUNT>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
+    if (mg.done) {
+        pos = mg.pos;
+        t = mg.t;
+        mg.done = false;
+    } else {
+        traverse<Q_CLOSEST, COUNT>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
+    }
     const bool hit = active && pos >= 0;
     if (active) {
         if (hit)
@@ -735,18 +781,27 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     }
 
     HitL h;
-    const V3 Lo = shade_hit<COUNT>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl);
-    if (hit) {
-        float* d = a.direct + (size_t)(level - first_level) * a.level_stride + 3 * (size_t)item;
-        d[0] = Lo.x, d[1] = Lo.y, d[2] = Lo.z;
-    }
+    h.normal = mk(0, 0, 1), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
+    h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
+    if (hit)
+        resolve_hit(sv, flags, ray, t, pos, h);
+    if (COUNT && hit)
+        rc.hits = 1;
 
-    // ---- reflection spawn (render.cpp:34,52-54,100,113-119) ---------------------
+    // ---- reflection spawn (render.cpp:34,52-54,100,113-119): known before the lights are
+    //      evaluated, so its ray can share a traversal with this level's shadow rays
     bool spawn = false;
     RayL refl;
     refl.o = mk(0, 0, 0), refl.d = mk(0, 0, 0);
     if (hit && (flags & F_RECURSIVE) && level < a.depth)
         spawn = compute_reflection_ray(ray, t, h, refl);
+    mg.spawn = spawn, mg.refl = refl;
+
+    const V3 Lo = shade_hit<COUNT, false>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, &mg);
+    if (hit) {
+        float* d = a.direct + (size_t)(level - first_level) * a.level_stride + 3 * (size_t)item;
+        d[0] = Lo.x, d[1] = Lo.y, d[2] = Lo.z;
+    }
     const uint64_t smask = ballot(spawn);
     if (COUNT && spawn)
         rc.queued = 1;
@@ -1055,7 +1110,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const IntersectArgs a)
         rc.closest = 1;
     __shared__ WaveLds lds[kBlock / 64];
     int32_t pos;
-    traverse<false, COUNT>(a.sv, (a.flags & F_ACCEL) != 0, (a.flags & F_NO_PRUNE) == 0, active, ray, t, pos, lc,
+    traverse<Q_CLOSEST, COUNT>(a.sv, (a.flags & F_ACCEL) != 0, (a.flags & F_NO_PRUNE) == 0, active, ray, t, pos, lc,
         lds[threadIdx.x >> 6]);
     if (active) {
         const bool hit = pos >= 0;

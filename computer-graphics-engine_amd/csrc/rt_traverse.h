@@ -22,6 +22,16 @@
 
 namespace rt {
 
+// Query mode of a traversal: closest hit, any hit (shadow query), or MIXED — ray slots 0..31
+// closest, slots 32..63 any hit (k_trace_level traces a level's shadow rays together with the
+// next level's reflection rays).
+enum : int { Q_CLOSEST = 0, Q_ANY = 1, Q_MIXED = 2 };
+template <int MODE>
+RT_DEV bool any_hit_slot(uint32_t r)
+{
+    return MODE == Q_ANY || (MODE == Q_MIXED && r >= 32u);
+}
+
 // ---- leaf phase -----------------------------------------------------------------
 #if defined(RT_DIAG) && RT_DIAG == 2
 __device__ const float4* g_diag_leaf;
@@ -69,12 +79,12 @@ RT_DEV void leaf_test_one(WaveLds& L, const float4 c[3], uint32_t r, uint32_t in
 // Ungrouped range [ref, ref + cnt) of `leaf` against ray slot r, the whole wave on it, one
 // primitive per lane: leaves above kGroupLeafMax primitives, scenes with spheres, a root that
 // is a leaf, and the brute-force mode (enableAccelStructure off: the whole array).
-template <bool ANY, bool COUNT>
+template <int MODE, bool COUNT>
 RT_DEV void flat_range(WaveLds& L, BufRsrc leaf, bool spheres, uint32_t r, uint32_t ref, uint32_t cnt, uint32_t lane,
     LaneCounters& lc)
 {
     for (uint32_t base = 0; base < cnt; base += 64u) {
-        if (ANY && L.best[r] != kNoHit)
+        if (any_hit_slot<MODE>(r) && L.best[r] != kNoHit)
             break;
         const uint32_t i = base + lane;
         if (i < cnt) {
@@ -106,7 +116,7 @@ RT_DEV bool group_may_hit(float4 g0, float4 g1, float4 ra, float4 rb, float4 rc,
 //           box test (pruned policy), survivors appended to an LDS list together with the
 //           group's four ranks.
 //  Stage B: 4 lanes per surviving group, one triangle per lane: the reference's exact test.
-template <bool ANY, bool COUNT>
+template <int MODE, bool COUNT>
 RT_DEV void leaf_phase(WaveLds& L, BufRsrc leafg, BufRsrc groups, uint32_t first, uint32_t n, uint32_t lane, bool prune,
     LaneCounters& lc)
 {
@@ -118,7 +128,7 @@ RT_DEV void leaf_phase(WaveLds& L, BufRsrc leafg, BufRsrc groups, uint32_t first
             const uint32_t pi = (e >> 3) & 0xffu, g = e & 7u;
             const uint32_t refw = L.lq_ref[pi], cw = L.lq_cw[pi];
             const uint32_t r = refw >> 26;
-            if (rank != 31u && !(ANY && L.best[r] != kNoHit)) {
+            if (rank != 31u && !(any_hit_slot<MODE>(r) && L.best[r] != kNoHit)) {
                 float4 c[3];
                 load_leaf(leafg, ((cw >> 6) + g) * 4u + j, c);
 #if defined(RT_DIAG) && RT_DIAG == 2 // the same three loads from a second copy of the leaf array
@@ -145,8 +155,9 @@ RT_DEV void leaf_phase(WaveLds& L, BufRsrc leafg, BufRsrc groups, uint32_t first
             const uint32_t refw = L.lq_ref[first + p], cw = L.lq_cw[first + p];
             const float lb = L.lq_lb[first + p];
             const uint32_t r = refw >> 26;
-            const float lim = ANY ? L.rayB[r].z : ray_limit(L, r);
-            const bool skip = ANY ? (L.best[r] != kNoHit) : (prune && lb > lim);
+            const bool any = any_hit_slot<MODE>(r);
+            const float lim = any ? L.rayB[r].z : ray_limit(L, r);
+            const bool skip = any ? (L.best[r] != kNoHit) : (prune && lb > lim);
             if (g * 4u < (cw & 63u) && !skip) {
                 const uint32_t off = ((cw >> 6) + g) * 32u;
                 const float4 g0 = buf_load16(groups, off), g1 = buf_load16(groups, off + 16u);
@@ -179,7 +190,7 @@ RT_DEV void leaf_phase(WaveLds& L, BufRsrc leafg, BufRsrc groups, uint32_t first
 }
 
 // State shared by the engines of one traverse() call.
-template <bool ANY, bool COUNT>
+template <int MODE, bool COUNT>
 struct Walk {
     const SceneView& sv;
     WaveLds& L;
@@ -223,9 +234,9 @@ struct Walk {
                 big &= big - 1;
                 const uint32_t rr = read_lane(r, src), bref = read_lane(ref, src), bcnt = cw_big_count(read_lane(cw, src));
                 const float blb = __uint_as_float(read_lane(__float_as_uint(lb), src));
-                if (ANY ? (L.best[rr] != kNoHit) : (prune && blb > ray_limit(L, rr)))
+                if (any_hit_slot<MODE>(rr) ? (L.best[rr] != kNoHit) : (prune && blb > ray_limit(L, rr)))
                     continue;
-                flat_range<ANY, COUNT>(L, leaf, spheres, rr, bref, bcnt, lane, lc);
+                flat_range<MODE, COUNT>(L, leaf, spheres, rr, bref, bcnt, lane, lc);
             }
             want = want && !cw_is_big(cw);
         }
@@ -253,7 +264,7 @@ struct Walk {
             while (lq_n > 0u) {
                 const uint32_t n = lq_n < 64u ? lq_n : 64u;
                 lq_n -= n;
-                leaf_phase<ANY, COUNT>(L, leafg, groups, lq_n, n, lane, prune, lc);
+                leaf_phase<MODE, COUNT>(L, leafg, groups, lq_n, n, lane, prune, lc);
             }
             wave_lds_fence();
 #ifdef RT_STAMPS
@@ -273,7 +284,7 @@ struct Walk {
             lc.node_fetch++;
         }
         if (prune) { // shadow rays: against the initial limit (t0 = 1)
-            const float lim = ANY ? L.rayB[r].z : ray_limit(L, r);
+            const float lim = any_hit_slot<MODE>(r) ? L.rayB[r].z : ray_limit(L, r);
             hl = hl && !(lb_l > lim);
             hr = hr && !(lb_r > lim);
         }
@@ -345,7 +356,7 @@ struct Walk {
                 have = false;
                 const float e_lb = entry_lb(e);
                 r = entry_ray(e);
-                const bool skip = ANY ? (L.best[r] != kNoHit) : (prune && e_lb > ray_limit(L, r));
+                const bool skip = any_hit_slot<MODE>(r) ? (L.best[r] != kNoHit) : (prune && e_lb > ray_limit(L, r));
                 if (!skip) {
                     load_ray(r);
                     const uint32_t noff = entry_node(e) * 64u;
@@ -406,15 +417,15 @@ struct Walk {
 };
 
 // ---- traversal ------------------------------------------------------------------
-// ANY = false: closest hit ≙ BoundingVolumeHierarchy::intersect's traversal
+// MODE Q_CLOSEST: closest hit ≙ BoundingVolumeHierarchy::intersect's traversal
 //   (bvh.cpp:299-362) + getIntersecting (:272-293): `t` holds ray.t in/out, `pos`
 //   the array index of the reported primitive (-1: none).
-// ANY = true: shadow query (light.cpp:61-67 only uses the boolean): `t` is the
+// MODE Q_ANY: shadow query (light.cpp:61-67 only uses the boolean): `t` is the
 //   limit (1.0), pos >= 0 iff something blocks the ray.
 // `active` selects the lanes that carry a ray; ALL lanes of the wave must call.
 // use_bvh = features.enableAccelStructure; when false the whole array is one leaf
 // in the reference's own order (bvh.cpp:303-305; sv.leaf_flat).
-template <bool ANY, bool COUNT>
+template <int MODE, bool COUNT>
 RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active, const RayL& ray, float& t,
     int32_t& pos, LaneCounters& lc, WaveLds& L)
 {
@@ -432,7 +443,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t, __uint_as_float(inv.guard));
     L.rayC[lane] = make_float4(inv.y[0], inv.y[1], inv.y[2], inv.slack);
     L.best[lane] = kNoHit;
-    Walk<ANY, COUNT> w { sv, L, make_rsrc(use_bvh ? sv.leaf : sv.leaf_flat, sv.n_prims * 48u),
+    Walk<MODE, COUNT> w { sv, L, make_rsrc(use_bvh ? sv.leaf : sv.leaf_flat, sv.n_prims * 48u),
         make_rsrc(sv.nodes, sv.n_pairs * 64u), make_rsrc(sv.leaf_grouped, sv.n_groups * 4u * 48u),
         make_rsrc(sv.groups, sv.n_groups * 32u), sv.prune_ok == 0u, lc, lane, prune, 0u, ray, inv, lane };
 #ifdef RT_STAMPS
@@ -448,7 +459,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     const unsigned long long key = L.best[lane];
     if (active && key != kNoHit) {
         pos = (int32_t)key_index(key);
-        if (!ANY) { // the reported primitive's own t, with its exact bits (-0.0f included)
+        if (!any_hit_slot<MODE>(lane)) { // the reported primitive's own t, with its exact bits (-0.0f included)
             const PrimRecord rec = (use_bvh ? sv.prims : sv.prims_flat)[pos];
             float tt;
             if (rec.kind_mat & 0x80000000u)
@@ -462,7 +473,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
 #ifdef RT_STAMPS
     if (sv.stamps && lane == 0) {
         const unsigned long long total = clock64() - stamp_begin;
-        const int base = ANY ? 8 : 0;
+        const int base = MODE == Q_ANY ? 8 : 0;
         atomicAdd(&sv.stamps[base + 0], w.st_steal);
         atomicAdd(&sv.stamps[base + 1], w.st_node);
         atomicAdd(&sv.stamps[base + 2], w.st_leaf);
@@ -471,7 +482,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
         atomicAdd(&sv.stamps[base + 5], w.n_leaf);
         atomicAdd(&sv.stamps[base + 6], 1ull);
         atomicMax(&sv.stamps[base + 7], total);
-        if (!ANY) {
+        if (MODE != Q_ANY) {
             atomicAdd(&sv.stamps[16], w.st_pop);
             atomicAdd(&sv.stamps[17], w.st_load);
             atomicAdd(&sv.stamps[18], w.st_alu);
