@@ -103,3 +103,32 @@ def test_c4_area_light_statistics(rt, scenes, full):
     blocks = lambda x: x[: H // 16 * 16, : W // 16 * 16].reshape(H // 16, 16, W // 16, 16, 3).mean(axis=(1, 3))
     diff = np.abs(blocks(a) - blocks(b))
     assert diff.mean() < 2e-3
+
+
+def test_leaves_above_32_primitives_take_the_ungrouped_path(rt, oracle, abi, scenes):
+    """MAX_DEPTH caps the tree at 2^15 leaves: a 1.3 M-triangle mesh gets ~40 triangles per leaf,
+    above the culling groups' limit of 32 (rt_layout.h kGroupLeafMax), so the traversal tests
+    those leaves whole, like the reference. Hit records bit-identical, colours within tolerance,
+    pruned == unpruned."""
+    data = scenes.get_scene("knot", n_u=4096, n_v=160)       # 1 310 720 triangles
+    assert data.n_triangles > 32 * (1 << 15)
+    f = abi.Features.make(enableShading=1, enableRecursive=1, enableHardShadow=1, enableAccelStructure=1)
+    p = abi.RenderParams.make(depth=2)
+    bvh = rt.bvh(rt.scene(data), f)
+    ob = oracle.build(data, f)
+    assert bvh.num_leaves == ob.num_leaves and bvh.num_levels == ob.num_levels
+    W, H = 160, 96
+    args = scenes.default_camera_args(W, H)
+    cam, ocam = rt.camera(*args), oracle.camera(*args)
+    tb, pr = rt.render_hits(bvh, cam, f, W, H)
+    orgb, otb, opr, _ = oracle.render(ob, ocam, f, p, W, H, want_hits=True)
+    assert (opr >= 0).sum() > 500
+    assert np.array_equal(pr, opr) and np.array_equal(tb, otb)
+    rgb = rt.render(bvh, cam, f, p, W, H)
+    assert_colors_close(rgb, orgb)
+    rt.set_option("unpruned", 1)
+    try:
+        ref_policy = rt.render(bvh, cam, f, p, W, H)
+    finally:
+        rt.set_option("unpruned", 0)
+    assert np.array_equal(bits(ref_policy), bits(rgb))
