@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 }, g_fused_from { 0 }, g_merge_next { 1 };
+std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -178,6 +178,12 @@ struct rt_bvh {
         v.bounds_finite = host.bounds_finite ? 1u : 0u;
         v.prune_ok = scene->host.spheres.empty() ? 1u : 0u;
         v.extent = scene->host.extent;
+        if (!host.nodes.empty()) { // post-order: the root is last
+            memcpy(v.scene_lo, host.nodes.back().lo, 12);
+            memcpy(v.scene_hi, host.nodes.back().hi, 12);
+        } else {
+            memset(v.scene_lo, 0, 12), memset(v.scene_hi, 0, 12);
+        }
         v.leaf_flush = (uint32_t)g_leaf_flush.load();
         v.stamps = g_stamps;
 #ifdef RT_DIAG
@@ -347,6 +353,7 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     const int32_t fused_from = fused ? std::min(g_fused_from.load(), n_levels - 1) : n_levels;
     a.prio_levels = g_prio.load() ? 1u : 0u;
     a.merge_next = g_merge_next.load() ? 1u : 0u;
+    a.tile_cull = g_tile_cull.load() && !counters_dev ? 1u : 0u; // the counting pass traces every primary ray
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
     if (source == rt::SRC_CAMERA) {
@@ -515,6 +522,10 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "prio") == 0) { // 1: deeper recursion levels get a higher wave priority (default)
         g_prio.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "tile_cull") == 0) { // 1: a primary tile whose rays cannot reach the scene bounds is finished at once
+        g_tile_cull.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "merge_next") == 0) { // 1: shadow rays of level k share a traversal with the reflection rays of level k + 1

@@ -69,6 +69,7 @@ struct LevelArgs {
     ShareArgs share;
     uint32_t prio_levels;     // 1: s_setprio by recursion level (deeper = higher)
     uint32_t merge_next;      // 1: trace a level's first shadow rays together with the next level's reflection rays
+    uint32_t tile_cull;       // 1: primary tiles that cannot reach the scene bounds skip the traversal
     RaySoA out;
     uint32_t* out_count;
     float* direct;   // this level's direct-light colours, n_items * 3

@@ -136,6 +136,59 @@ RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_
     return ok;
 }
 
+RT_DEV float wave_min_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+RT_DEV float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Can no primary ray of this tile come near the scene? The tile's rays lie inside the pyramid
+// spanned by the four corner positions of its pixels' bounding rectangle (the direction is
+// linear in the screen position before normalisation); if all eight corners of the scene
+// bounds — grown by 2^-10 of the scene scale, three orders above the pruning slack and the
+// rounding of these dot products — lie outside one of the pyramid's side planes, no ray can
+// produce a candidate (same lemma as pruning: a candidate's point lies within rho of its
+// triangle). Lanes 0..31 evaluate plane (lane & 3) against box corner (lane >> 2). Wave-uniform.
+RT_DEV bool tile_misses_scene(const CameraArgs& c, const SceneView& sv, bool active, int32_t x, int32_t y)
+{
+    const uint32_t lane = lane_id();
+    const float px = float(x) / float(c.width) * 2.0f - 1.0f, py = float(y) / float(c.height) * 2.0f - 1.0f;
+    const float inf = __builtin_inff();
+    const float px0 = wave_min_f(active ? px : inf), px1 = wave_max_f(active ? px : -inf);
+    const float py0 = wave_min_f(active ? py : inf), py1 = wave_max_f(active ? py : -inf);
+    auto corner = [&](uint32_t k) {
+        const float cx = (k == 0u || k == 3u) ? px0 : px1, cy = k < 2u ? py0 : py1;
+        return quat_rotate(c.quat, mk(-cx * c.half_w, cy * c.half_h, 1.0f));
+    };
+    const uint32_t k = lane & 3u;
+    const V3 c0 = corner(k), c1 = corner((k + 1u) & 3u);
+    const V3 mid = quat_rotate(c.quat, mk(-(0.5f * (px0 + px1)) * c.half_w, (0.5f * (py0 + py1)) * c.half_h, 1.0f));
+    V3 n = cross(c0, c1);
+    if (dot(n, mid) < 0.0f)
+        n = -n; // inside = positive side
+    const float S = fmaxf(sv.extent, fmaxf(fabsf(c.origin[0]), fmaxf(fabsf(c.origin[1]), fabsf(c.origin[2]))));
+    const float g = S * 0.0009765625f;
+    const uint32_t bc = lane >> 2;
+    const V3 P = mk((bc & 1u) ? sv.scene_hi[0] + g : sv.scene_lo[0] - g, (bc & 2u) ? sv.scene_hi[1] + g : sv.scene_lo[1] - g,
+        (bc & 4u) ? sv.scene_hi[2] + g : sv.scene_lo[2] - g);
+    const float side = dot(n, P - mk(c.origin[0], c.origin[1], c.origin[2]));
+    const uint32_t outside = (uint32_t)(ballot(lane < 32u && side < 0.0f) & 0xffffffffull); // NaN: not outside
+    bool miss = false;
+#pragma unroll
+    for (uint32_t p = 0; p < 4u; p++)
+        miss = miss || ((outside >> p) & 0x11111111u) == 0x11111111u;
+    return miss;
+}
+
 RT_DEV uint32_t wave_sum(uint32_t v)
 {
 #pragma unroll
@@ -664,9 +717,16 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     if (a.source == SRC_CAMERA) {
         int32_t x, y, lrow;
         active = tile_pixel(a.cam, wave, lane, x, y, lrow);
+        if (active)
+            item = (uint32_t)lrow * (uint32_t)a.cam.vwidth + (uint32_t)x; // x: virtual column (pixel * spp + sample)
+        if (!COUNT && a.tile_cull && a.level == 0 && a.cam.spp == 1 && a.cam.dof_n == 0 && use_bvh && prune
+            && sv.prune_ok != 0u && tile_misses_scene(a.cam, sv, active, x, y)) {
+            if (active)
+                a.state[item] = 0u; // every primary ray of the tile misses: vec3(0) (render.cpp:149-150)
+            return;
+        }
         if (active) {
             ray = camera_ray(a.cam, x, y);
-            item = (uint32_t)lrow * (uint32_t)a.cam.vwidth + (uint32_t)x; // x: virtual column (pixel * spp + sample)
             pixel = (uint32_t)y * (uint32_t)a.cam.vwidth + (uint32_t)x;  // RNG key of the light samples
         }
     } else {

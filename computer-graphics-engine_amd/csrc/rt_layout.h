@@ -145,6 +145,7 @@ struct SceneView {
     uint32_t bounds_finite; // no node bound is NaN / infinite (rt_device.h: box_pair_hit fast path)
     uint32_t prune_ok; // 0 when the scene holds spheres (rt_device.h: Pruning)
     float extent;      // largest |coordinate| of any vertex
+    float scene_lo[3], scene_hi[3]; // bounds of the root node (all primitives)
     unsigned long long* stamps; // diagnostic builds (-DRT_STAMPS) only, else NULL
 #ifdef RT_DIAG // diagnostic builds: second copies at other addresses (tools/diag.sh)
     const NodePair* diag_nodes;
