@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 };
+std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -263,6 +263,7 @@ rt::CameraArgs camera_args(const rt_camera& c, int32_t w, int32_t h)
     a.super_log = (uint32_t)g_super_log.load();
     a.order = nullptr;
     a.vwidth = w, a.spp = 1, a.ms_n = 0, a.dof_n = 0;
+    a.tile_x0 = a.tile_y0 = a.tiles_w = a.tiles_h = 0;
     memcpy(a.look_at, c.look_at, 12);
     a.focus = 0.0f, a.blur = 0.0f, a.seed = 0u;
     return a;
@@ -285,31 +286,101 @@ void camera_samples(rt::CameraArgs& a, const rt_features& f, const rt_render_par
 // one wave's serial work; tiles that see geometry (usually around the centre) must start
 // early or their chains form a tail with most of the chip idle (tools/timeline.py: half of
 // the launch on the bench scene). Purely a scheduling choice — results do not depend on it.
+// Launch only the tiles that can see the scene: the screen-space bounding rectangle of the
+// (grown) scene bounds, two pixels wider on every side. Starting a one-wave workgroup costs
+// ~1.9 ns of dispatcher time even if it exits at once (129 600 empty workgroups: 0.24 ms,
+// tools/empty_frame.py), so tiles that cannot produce a hit are not launched at all; their
+// pixels keep state 0 (= vec3(0)) from a memset. Conservative like tile_misses_scene, which
+// still runs on the launched tiles. Returns false when the whole grid has to be launched.
+bool host_launch_rect(const rt_bvh* bvh, rt::CameraArgs& cam)
+{
+    if (!g_tile_cull.load() || !g_launch_rect.load() || cam.super_log != 0 || cam.dof_n != 0 || bvh->host.nodes.empty()
+        || !bvh->scene->host.spheres.empty())
+        return false;
+    const rt::RefNode& root = bvh->host.nodes.back();
+    double S = bvh->scene->host.extent;
+    for (int a = 0; a < 3; a++)
+        S = std::max(S, (double)std::fabs(cam.origin[a]));
+    const double g = S * 0.0009765625;
+    // inverse camera rotation: conj(q) * v * q
+    const double qw = cam.quat[0], qx = -cam.quat[1], qy = -cam.quat[2], qz = -cam.quat[3];
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int k = 0; k < 8; k++) {
+        const double P[3] = { ((k & 1) ? root.hi[0] + g : root.lo[0] - g) - cam.origin[0],
+            ((k & 2) ? root.hi[1] + g : root.lo[1] - g) - cam.origin[1],
+            ((k & 4) ? root.hi[2] + g : root.lo[2] - g) - cam.origin[2] };
+        const double uv[3] = { qy * P[2] - P[1] * qz, qz * P[0] - P[2] * qx, qx * P[1] - P[0] * qy };
+        const double uuv[3] = { qy * uv[2] - uv[1] * qz, qz * uv[0] - uv[2] * qx, qx * uv[1] - uv[0] * qy };
+        const double c[3] = { P[0] + (uv[0] * qw + uuv[0]) * 2.0, P[1] + (uv[1] * qw + uuv[1]) * 2.0,
+            P[2] + (uv[2] * qw + uuv[2]) * 2.0 };
+        if (!(c[2] > 1e-6 * S)) // a corner at or behind the camera plane: no finite rectangle
+            return false;
+        const double px = -c[0] / (c[2] * cam.half_w), py = c[1] / (c[2] * cam.half_h);
+        const double x = (px + 1.0) * 0.5 * cam.width, y = (py + 1.0) * 0.5 * cam.height;
+        xmin = std::min(xmin, x), xmax = std::max(xmax, x), ymin = std::min(ymin, y), ymax = std::max(ymax, y);
+    }
+    if (!(xmin == xmin) || !(ymin == ymin))
+        return false;
+    const int64_t tw = 1 << cam.tile_wlog, th = 1 << cam.tile_hlog;
+    const int64_t tiles_x = (cam.vwidth + tw - 1) / tw, tiles_y = (cam.n_rows + th - 1) / th;
+    int64_t x0 = (int64_t)std::floor(xmin) - 2, x1 = (int64_t)std::ceil(xmax) + 2; // pixel columns, inclusive
+    int64_t y0 = (int64_t)std::floor(ymin) - 2, y1 = (int64_t)std::ceil(ymax) + 2;
+    x0 = std::max<int64_t>(x0, 0), x1 = std::min<int64_t>(x1, cam.width - 1);
+    y0 = std::max<int64_t>(y0, 0), y1 = std::min<int64_t>(y1, cam.height - 1);
+    int64_t tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    if (x0 <= x1 && y0 <= y1) {
+        tx0 = (x0 * cam.spp) / tw, tx1 = ((x1 + 1) * cam.spp - 1) / tw;
+        if (cam.rows) { // an arbitrary row list: keep every tile row
+            ty0 = 0, ty1 = tiles_y - 1;
+        } else {
+            const int64_t l0 = std::max<int64_t>(y0 - cam.row0, 0), l1 = std::min<int64_t>(y1 - cam.row0, cam.n_rows - 1);
+            if (l0 <= l1)
+                ty0 = l0 / th, ty1 = l1 / th;
+        }
+    }
+    cam.tile_x0 = (uint32_t)tx0, cam.tile_y0 = (uint32_t)ty0;
+    cam.tiles_w = (uint32_t)std::max<int64_t>(tx1 - tx0 + 1, 0), cam.tiles_h = (uint32_t)std::max<int64_t>(ty1 - ty0 + 1, 0);
+    if (cam.tiles_w == 0 || cam.tiles_h == 0) { // nothing can be hit: one (culled) tile keeps the launch path uniform
+        cam.tile_x0 = cam.tile_y0 = 0;
+        cam.tiles_w = cam.tiles_h = 1;
+    }
+    return !(cam.tiles_w == (uint32_t)tiles_x && cam.tiles_h == (uint32_t)tiles_y);
+}
+
+// Dispatch order of the launched tiles: rings around the centre of the launched grid, innermost
+// first (O(n), no sort: the grid changes with the camera). Workgroups start in index order, and
+// with the recursion fused into one launch a tile's whole path tree is one wave's serial work;
+// tiles that see geometry (around the centre of the scene's screen rectangle) must start early
+// or their chains form a tail with most of the chip idle (tools/timeline.py). Purely a
+// scheduling choice — results do not depend on it.
 int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
 {
     if (!g_tile_order.load() || cam.super_log != 0)
         return RT_OK;
     const int64_t tw = 1 << cam.tile_wlog, th = 1 << cam.tile_hlog;
-    const int64_t tiles_x = (cam.vwidth + tw - 1) / tw, tiles_y = (cam.n_rows + th - 1) / th;
-    std::vector<int64_t> key { cam.vwidth, cam.height, cam.n_rows, cam.row0, tw, th, cam.rows ? 1 : 0 };
-    if (cam.rows)
-        key.insert(key.end(), sc.rows_host.begin(), sc.rows_host.end());
+    const int64_t gw = cam.tiles_w ? cam.tiles_w : (cam.vwidth + tw - 1) / tw;
+    const int64_t gh = cam.tiles_w ? cam.tiles_h : (cam.n_rows + th - 1) / th;
+    // tiles are tw x th pixels: measure rings in pixels so that they are round on the screen
+    // ring centre: the image centre, in tiles of the launched grid (may lie outside it)
+    const int64_t lrow_mid = cam.rows ? cam.n_rows / 2 : std::min<int64_t>(std::max<int64_t>(cam.height / 2 - cam.row0, 0), cam.n_rows - 1);
+    const int64_t cx = (cam.vwidth / 2) / tw - (int64_t)cam.tile_x0, cy = lrow_mid / th - (int64_t)cam.tile_y0;
+    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy };
     if (key != sc.order_key || !sc.order.p) {
-        const size_t n = (size_t)(tiles_x * tiles_y);
-        std::vector<std::pair<int64_t, uint32_t>> d(n);
-        for (int64_t ty = 0; ty < tiles_y; ty++) {
-            const int64_t lrow = std::min<int64_t>(ty * th + th / 2, cam.n_rows - 1);
-            const int64_t y = cam.rows ? sc.rows_host[(size_t)lrow] : cam.row0 + lrow;
-            for (int64_t tx = 0; tx < tiles_x; tx++) {
-                const int64_t x = tx * tw + tw / 2;
-                const int64_t dx = 2 * x - cam.vwidth, dy = 2 * y - cam.height;
-                d[(size_t)(ty * tiles_x + tx)] = { dx * dx + dy * dy, (uint32_t)(ty * tiles_x + tx) };
+        const size_t n = (size_t)(gw * gh);
+        std::vector<uint32_t> order;
+        order.reserve(n);
+        const int64_t rmax = std::max(std::max(std::llabs(cx), std::llabs(gw - 1 - cx)) * tw,
+            std::max(std::llabs(cy), std::llabs(gh - 1 - cy)) * th);
+        const int64_t step = std::min(tw, th);
+        // ring r holds the tiles whose pixel offset (|dx| * tw, |dy| * th) has Chebyshev length in (r - step, r]
+        std::vector<std::vector<uint32_t>> rings((size_t)(rmax / step + 2));
+        for (int64_t ty = 0; ty < gh; ty++)
+            for (int64_t tx = 0; tx < gw; tx++) {
+                const int64_t r = std::max(std::llabs(tx - cx) * tw, std::llabs(ty - cy) * th);
+                rings[(size_t)((r + step - 1) / step)].push_back((uint32_t)(ty * gw + tx));
             }
-        }
-        std::sort(d.begin(), d.end());
-        std::vector<uint32_t> order(n);
-        for (size_t i = 0; i < n; i++)
-            order[i] = d[i].second;
+        for (const auto& ring : rings)
+            order.insert(order.end(), ring.begin(), ring.end());
         HIP_TRY(sc.order.reserve(n));
         HIP_TRY(hipMemcpyAsync(sc.order.p, order.data(), n * 4, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream)); // `order` is a local
@@ -357,6 +428,15 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
     if (source == rt::SRC_CAMERA) {
+        // the counting pass traces every primary ray; otherwise launch only the tiles that can see the scene
+        if (!counters_dev && (flags & rt::F_ACCEL) && !(flags & rt::F_NO_PRUNE) && host_launch_rect(bvh, a.cam)) {
+            // k_fold treats the items of tiles outside the launched grid as untraced (vec3(0))
+            fold.vwidth = (uint32_t)a.cam.vwidth, fold.tile_wlog = a.cam.tile_wlog, fold.tile_hlog = a.cam.tile_hlog;
+            fold.tile_x0 = a.cam.tile_x0, fold.tile_y0 = a.cam.tile_y0;
+            fold.tiles_w = a.cam.tiles_w, fold.tiles_h = a.cam.tiles_h;
+        } else {
+            a.cam.tile_x0 = a.cam.tile_y0 = a.cam.tiles_w = a.cam.tiles_h = 0;
+        }
         const int rc = tile_order_for(sc, a.cam, stream);
         if (rc != RT_OK)
             return rc;
@@ -522,6 +602,10 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "prio") == 0) { // 1: deeper recursion levels get a higher wave priority (default)
         g_prio.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "launch_rect") == 0) { // 1: launch only the tiles inside the scene's screen rectangle
+        g_launch_rect.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "tile_cull") == 0) { // 1: a primary tile whose rays cannot reach the scene bounds is finished at once

@@ -28,6 +28,9 @@ struct CameraArgs {
     uint32_t tile_wlog, tile_hlog; // primary tile = 2^wlog x 2^hlog pixels per wave (<= 64)
     uint32_t super_log;            // > 0: super-tiles of 2^s x 2^s tiles dealt to the XCDs (tile_pixel)
     const uint32_t* order;         // NULL, or launch position -> tile index (heavy-first dispatch order)
+    // launched sub-grid of tiles (host_launch_rect): tiles [tile_x0, tile_x0 + tiles_w) x [tile_y0, tile_y0 + tiles_h);
+    // tiles_w == 0 means the whole grid
+    uint32_t tile_x0, tile_y0, tiles_w, tiles_h;
     // samples per pixel (src/render.cpp:295-314): ms_n x ms_n jittered rays, then dof_n lens rays;
     // the launch sees a VIRTUAL image of vwidth = width * spp columns, column x * spp + s = sample s of pixel x
     int32_t vwidth, spp, ms_n, dof_n;
@@ -96,6 +99,8 @@ struct FoldArgs {
     int32_t width, height, row0, packed;
     const int32_t* rows;
     float* out;
+    // launched sub-grid (CameraArgs::tiles_w != 0): items of tiles outside it were never traced = vec3(0)
+    uint32_t vwidth, tile_wlog, tile_hlog, tile_x0, tile_y0, tiles_w, tiles_h;
 };
 
 // Per-pixel combination of the samples (renderRayTracing, src/render.cpp:295-322) — k_resolve

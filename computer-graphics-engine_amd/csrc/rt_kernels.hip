@@ -115,7 +115,12 @@ RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_
     if (c.super_log == 0) {
         if (c.order)
             wave = c.order[wave];
-        ty = wave / tiles_x, tx = wave - ty * tiles_x;
+        if (c.tiles_w) { // launched sub-grid
+            ty = wave / c.tiles_w, tx = wave - ty * c.tiles_w;
+            tx += c.tile_x0, ty += c.tile_y0;
+        } else {
+            ty = wave / tiles_x, tx = wave - ty * tiles_x;
+        }
     } else {
         const uint32_t s = c.super_log, wpb = kBlock / 64;
         const uint32_t bpc = (1u << (2 * s)) / wpb; // workgroups per super-tile
@@ -427,7 +432,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
     uint32_t n_units;
     if (a.source == SRC_CAMERA) {
         const uint32_t tw = 1u << a.cam.tile_wlog, th = 1u << a.cam.tile_hlog;
-        n_units = (((uint32_t)a.cam.vwidth + tw - 1u) >> a.cam.tile_wlog) * (((uint32_t)a.cam.n_rows + th - 1u) >> a.cam.tile_hlog);
+        n_units = a.cam.tiles_w ? a.cam.tiles_w * a.cam.tiles_h
+                                : (((uint32_t)a.cam.vwidth + tw - 1u) >> a.cam.tile_wlog) * (((uint32_t)a.cam.n_rows + th - 1u) >> a.cam.tile_hlog);
     } else {
         n_units = (a.in_count_imm + 63u) / 64u;
     }
@@ -1035,7 +1041,15 @@ __global__ __launch_bounds__(256) void k_fold(const FoldArgs a)
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;
     if (item >= a.n_items)
         return;
-    const uint32_t s = a.state[item];
+    uint32_t s = 0u;
+    bool traced = true;
+    if (a.tiles_w) { // only the tiles inside the scene's screen rectangle were launched
+        const uint32_t lrow = item / a.vwidth, xv = item - lrow * a.vwidth;
+        const uint32_t tx = xv >> a.tile_wlog, ty = lrow >> a.tile_hlog;
+        traced = tx >= a.tile_x0 && tx - a.tile_x0 < a.tiles_w && ty >= a.tile_y0 && ty - a.tile_y0 < a.tiles_h;
+    }
+    if (traced)
+        s = a.state[item];
     const int32_t n = (int32_t)(s & 0xffu);
     V3 c = mk(0.0f, 0.0f, 0.0f);
     if (n > 0) {
@@ -1280,7 +1294,7 @@ uint64_t camera_waves(const CameraArgs& c)
     const uint32_t tw = 1u << c.tile_wlog, th = 1u << c.tile_hlog;
     const uint64_t tiles_x = (c.vwidth + tw - 1) / tw, tiles_y = (c.n_rows + th - 1) / th;
     if (c.super_log == 0)
-        return tiles_x * tiles_y;
+        return c.tiles_w ? (uint64_t)c.tiles_w * c.tiles_h : tiles_x * tiles_y;
     const uint32_t s = c.super_log;
     const uint64_t chunks = ((tiles_x + (1u << s) - 1) >> s) * ((tiles_y + (1u << s) - 1) >> s);
     return ((chunks + 7) / 8 * 8) << (2 * s); // whole super-tiles, a multiple of 8 of them (tile_pixel)
