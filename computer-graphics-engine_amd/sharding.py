@@ -68,7 +68,11 @@ class StripRenderer:
     device is synchronised (`finish()`)."""
 
     def __init__(self, rt, bvh, cam, features, params, width, height, rank=0, world=1, strip_rows=8,
-                 overlap=True):
+                 overlap=True, frames_in_flight=1):
+        """frames_in_flight > 1 (one rank only): successive frames go to alternating HIP streams, each
+        with its own frame buffer and library scratch, so the tail of frame k — a few long path trees
+        on an otherwise idle chip — overlaps the start of frame k + 1. Every frame is rendered in
+        full; `frame` is the newest one after finish()."""
         import torch
 
         self.rt, self.bvh, self.cam, self.f, self.p = rt, bvh, cam, features, params
@@ -78,6 +82,10 @@ class StripRenderer:
         self.counters = torch.zeros(16, dtype=torch.int64, device="cuda")
         self.overlap = overlap and world > 1
         self.k = 0
+        self.flight = max(1, int(frames_in_flight)) if world == 1 else 1
+        if self.flight > 1:
+            self.streams = [torch.cuda.Stream() for _ in range(self.flight)]
+            self.frames = [self.frame] + [torch.zeros_like(self.frame) for _ in range(self.flight - 1)]
         # renderBloomFilter works on the WHOLE frame (render.cpp:326-328): with several ranks the
         # strips are rendered without it and every rank filters its assembled copy of the frame
         self.bloom = bool(features.enableBloomEffect) and world > 1
@@ -103,6 +111,16 @@ class StripRenderer:
         import torch
 
         if self.world == 1:
+            if self.flight > 1:
+                j = self.k % self.flight
+                self.k += 1
+                s = self.streams[j]
+                if self.k <= self.flight:
+                    s.wait_stream(torch.cuda.current_stream())  # whatever set the scene up has finished
+                self.frame = self.frames[j]
+                self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
+                                      stream=s.cuda_stream)
+                return
             self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
                                   stream=stream)
             return
@@ -135,6 +153,10 @@ class StripRenderer:
         import torch
 
         torch.cuda.synchronize()
+
+    def launch_streams(self, stream: int = 0):
+        """raw hipStream_t handles the frames are launched on (bench.py reads the kernel events of each)"""
+        return [s.cuda_stream for s in self.streams] if self.flight > 1 else [stream]
 
     def count_rays(self, stream: int = 0) -> dict:
         """One untimed frame of this rank's rows with the counting kernels."""
