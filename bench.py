@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="one rank only: successive frames on alternating HIP streams, so that the tail of frame k "
                          "(a few long path trees) overlaps the start of frame k + 1; 1 = strictly one frame at a time")
+    ap.add_argument("--tile-log", type=int, nargs=2, default=None, metavar=("W", "H"),
+                    help="primary tile = 2^W x 2^H pixels per wave (default: 2 3 with frames in flight, else the "
+                         "library's latency setting 1 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not bracket trace kernels with HIP events during the timed steps")
@@ -111,6 +114,15 @@ def main():
     cam = rt.camera(*scenes.default_camera_args(W, H))
 
     stream = torch.cuda.current_stream().cuda_stream
+    if args.tile_log:
+        rt.set_option("tile_wlog", args.tile_log[0])
+        rt.set_option("tile_hlog", args.tile_log[1])
+    elif world == 1 and args.frames_in_flight > 1:
+        # Throughput setting of the library's tuning knobs: 4x8-pixel primary tiles (32 rays per wave; with the
+        # merged traversals all 64 ray slots are used) do 30 % less instruction work than the latency setting
+        # (2x8) but end in longer path-tree tails — which the next frame in flight covers. Results are identical.
+        rt.set_option("tile_wlog", 2)
+        rt.set_option("tile_hlog", 3)
     renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, rank, world, strip_rows=STRIP_ROWS,
                                       frames_in_flight=args.frames_in_flight)
 

@@ -34,7 +34,8 @@ data = scenes.get_scene(cfg.scene)
 bvh = rt.bvh(rt.scene(data), f)
 cam = rt.camera(*scenes.default_camera_args(cfg.width, cfg.height))
 stream = torch.cuda.current_stream().cuda_stream
-R = sharding.StripRenderer(rt, bvh, cam, f, p, cfg.width, cfg.height)
+import os as _os
+R = sharding.StripRenderer(rt, bvh, cam, f, p, cfg.width, cfg.height, frames_in_flight=int(_os.environ.get('TUNE_FLIGHT', '1')))
 res = {v: [] for v in values}
 cnts = {}
 import os
