@@ -329,3 +329,67 @@ def test_bad_parameters_fail_loudly(rt, abi, scenes, built):
         with pytest.raises(capi.RtError) as e:
             rt.render(bvh, cam, f, abi.RenderParams.make(**bad), 32, 32)
         assert e.value.code == abi.RT_ERR_INVALID
+
+
+def _soup(abi, kind, rng):
+    """Synthetic meshes that stress the tie rule and the culling groups: duplicated triangles (every hit is
+    an exact tie: the reference reports the LATER one), a regular grid of coplanar quads hit exactly on shared
+    edges and vertices, degenerate (zero-area) triangles mixed in, many triangles in one plane (flat boxes)."""
+    if kind == "duplicates":
+        tri = rng.uniform(-1, 1, (700, 3, 3)).astype(np.float32) * np.float32(0.25) + rng.uniform(-1, 1, (700, 1, 3)).astype(np.float32)
+        tri = np.concatenate([tri, tri[::2], tri[::3]])                       # exact copies, interleaved by the builder
+    elif kind == "grid":
+        n = 24
+        xs = np.linspace(-1, 1, n + 1, dtype=np.float32)
+        gx, gy = np.meshgrid(xs, xs, indexing="ij")
+        quads = []
+        for i in range(n):
+            for j in range(n):
+                p00, p10 = (gx[i, j], gy[i, j], 0.0), (gx[i + 1, j], gy[i + 1, j], 0.0)
+                p11, p01 = (gx[i + 1, j + 1], gy[i + 1, j + 1], 0.0), (gx[i, j + 1], gy[i, j + 1], 0.0)
+                quads += [[p00, p10, p11], [p00, p11, p01]]
+        tri = np.array(quads, np.float32)
+    else:  # "degenerate"
+        tri = rng.uniform(-1, 1, (1500, 3, 3)).astype(np.float32) * np.float32(0.2) + rng.uniform(-1, 1, (1500, 1, 3)).astype(np.float32)
+        tri[::7, 2] = tri[::7, 1]                                              # two equal vertices
+        tri[::11] = tri[::11, :1]                                              # a point
+        tri[::13, :, 2] = np.float32(0.5)                                      # coplanar, axis-aligned plane
+    pos = tri.reshape(-1, 3)
+    idx = np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
+    mesh = abi.MeshData(pos, np.tile(np.float32([0, 0, 1]), (len(pos), 1)), np.zeros((len(pos), 2), np.float32), idx,
+                        abi.MaterialData((0.7, 0.6, 0.5), (0.3, 0.3, 0.3), 10.0, 1.0, -1))
+    return abi.SceneData(meshes=[mesh], lights=[abi.LightData.point((0.5, 0.8, -2.0), (1, 1, 1))], name=kind)
+
+
+@pytest.mark.parametrize("kind", ["duplicates", "grid", "degenerate"])
+@pytest.mark.parametrize("sah", [0, 1])
+def test_tie_and_degenerate_soups_bit_identical(rt, oracle, abi, kind, sah):
+    rng = np.random.default_rng(11)
+    data = _soup(abi, kind, rng)
+    f = abi.Features.make(enableAccelStructure=1, enableBvhSahBinning=sah)
+    bvh, ob = rt.bvh(rt.scene(data), f), oracle.build(data, f)
+    n = 8000
+    rays = make_rays(abi, rng, n, scale=2.5)
+    if kind == "grid":  # straight down onto grid vertices, edge midpoints and diagonals: exact ties
+        xs = np.linspace(-1, 1, 25, dtype=np.float32)
+        k = n // 2
+        px, py = rng.choice(xs, k), rng.choice(xs, k)
+        half = rng.integers(0, 3, k)
+        px = np.where(half == 1, px + np.float32(1 / 24), px).astype(np.float32)      # edge midpoints
+        both = half == 2
+        px = np.where(both, px + np.float32(1 / 24), px).astype(np.float32)           # on the diagonal x - y = const
+        py = np.where(both, py + np.float32(1 / 24), py).astype(np.float32)
+        rays["origin"][:k] = np.stack([px, py, np.full(k, -2, np.float32)], 1)
+        rays["direction"][:k] = np.float32([0, 0, 1])
+    got_rays, got = rt.intersect_batch(bvh, rays, f)
+    want_rays, want, _ = oracle.intersect_batch(ob, rays, f)
+    assert want["hit"].sum() > n // 50
+    assert np.array_equal(got["hit"], want["hit"])
+    assert np.array_equal(got["prim"], want["prim"]), f"{(got['prim'] != want['prim']).sum()} prim ids differ"
+    assert np.array_equal(bits(got["t"]), bits(want["t"]))
+    rt.set_option("unpruned", 1)
+    try:
+        _, ref_policy = rt.intersect_batch(bvh, rays, f)
+    finally:
+        rt.set_option("unpruned", 0)
+    assert np.array_equal(ref_policy["prim"], got["prim"]) and np.array_equal(bits(ref_policy["t"]), bits(got["t"]))
