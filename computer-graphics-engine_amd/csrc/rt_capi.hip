@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_share { 0 }, g_prio { 0 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
+std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_prio { 0 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -92,10 +92,6 @@ struct Scratch {
     DevBuf<float> samples;   // per-sample colours of multi-sample frames (k_resolve input)
     DevBuf<float> frames;    // k_trace_general: per-wave-slot recursion frames
     DevBuf<float> bloom_src; // the frame before the bloom filter
-    // tail work sharing of fused launches (rt_kernels.h ShareArgs)
-    DevBuf<uint32_t> share_sched;
-    DevBuf<unsigned long long> share_queue;
-    DevBuf<float4> share_rays;
     std::vector<int64_t> order_key;
     DevBuf<float> frame;      // device frame for host-output calls
     DevBuf<float> in_ray, in_t; // uploaded user rays
@@ -503,22 +499,6 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
             }
             HIP_TRY(hipEventRecord(sc.events[sc.events_used].first, stream));
         }
-        memset(&a.share, 0, sizeof(a.share));
-        if (a.fused && g_share.load() && n_levels > 1) {
-            // helpers + packets (k_trace_level "Helpers"): every word re-initialised per launch
-            constexpr uint32_t kQueueCap = 1u << 16, kQueueSlack = 1u << 14;
-            HIP_TRY(sc.share_sched.reserve(rt::SH_WORDS));
-            HIP_TRY(sc.share_queue.reserve(kQueueCap + kQueueSlack));
-            HIP_TRY(sc.share_rays.reserve(2 * (size_t)n_items));
-            a.share.sched = sc.share_sched.p;
-            a.share.queue = sc.share_queue.p;
-            a.share.rays = sc.share_rays.p;
-            a.share.queue_cap = kQueueCap;
-            a.share.ray_cap = n_items;
-            a.share.n_groups = rt::trace_level_groups(a);
-            HIP_TRY(hipMemsetAsync(sc.share_sched.p, 0, rt::SH_WORDS * sizeof(uint32_t), stream));
-            HIP_TRY(hipMemsetAsync(sc.share_queue.p, 0, (size_t)(kQueueCap + kQueueSlack) * sizeof(unsigned long long), stream));
-        }
         rt::launch_trace_level(a, counters_dev != nullptr, stream);
         if (bvh->profile) {
             HIP_TRY(hipEventRecord(sc.events[sc.events_used].second, stream));
@@ -620,10 +600,6 @@ int rt_set_option(const char* name, int value)
         if (value < 0 || value > 64)
             return fail(RT_ERR_INVALID, "rt_set_option: fused_from out of range");
         g_fused_from.store(value);
-        return RT_OK;
-    }
-    if (name && strcmp(name, "share") == 0) { // 1: tail work sharing between the waves of a fused launch (default)
-        g_share.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "tile_order") == 0) { // 1: centre-first dispatch of the primary tiles (default); 0: row-major

@@ -38,22 +38,6 @@ struct CameraArgs {
     uint32_t seed;
 };
 
-// Tail work sharing of a fused launch (k_trace_level, "Helpers"). All words are zeroed by
-// the launch function before every launch (pending preset to the grid size).
-// Per-wave bookkeeping (started / finished counts) is spread over 64 counters, one per
-// 256-byte line: 60 000 waves adding to ONE word serialise in its L2 channel (~50 ns each,
-// measured: the frame went from 1.5 to 5.8 ms). CLAIM / ALLOC / CREATED are touched in the tail only.
-enum : uint32_t {
-    SH_CLAIM = 0, SH_ALLOC = 1, SH_RAY_ALLOC = 2, SH_ERROR = 3, SH_CREATED = 4, SH_ALL_STARTED = 5,
-    SH_STARTED0 = 64, SH_FINISHED0 = 64 + 64 * 64, SH_SLOT_STRIDE = 64, SH_WORDS = 64 + 2 * 64 * 64
-};
-struct ShareArgs {
-    uint32_t* sched;           // SH_* words; NULL = sharing off
-    unsigned long long* queue; // packet descriptors, 0 = not published yet
-    float4* rays;              // payload: two float4 per ray (o.xyz d.x | d.y d.z item pixel)
-    uint32_t queue_cap, ray_cap, n_groups; // n_groups = workgroups of this launch
-};
-
 // One recursion level of the flattened Whitted recursion (k_trace_level).
 struct LevelArgs {
     SceneView sv;
@@ -69,7 +53,6 @@ struct LevelArgs {
     uint32_t min_waves;       // sparse levels: fewer rays per wave until this many waves are busy
     uint32_t fused;           // 1: the wave traces its own reflection rays, all levels in this launch
     size_t level_stride;      // floats between the `direct` planes of consecutive levels
-    ShareArgs share;
     uint32_t prio_levels;     // 1: s_setprio by recursion level (deeper = higher)
     uint32_t merge_next;      // 1: trace a level's first shadow rays together with the next level's reflection rays
     uint32_t tile_cull;       // 1: primary tiles that cannot reach the scene bounds skip the traversal

@@ -360,21 +360,6 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
     return Lo;
 }
 
-// agent-scope relaxed accesses to the work-sharing words (one lane)
-RT_DEV uint32_t sh_load(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-RT_DEV uint32_t sh_add(uint32_t* p, uint32_t v)
-{
-    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-RT_DEV uint64_t uni64(uint64_t v)
-{
-    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-}
-constexpr uint32_t kShareMinRays = 4;      // never split below this many rays per part
-constexpr uint32_t kShareMaxParts = 4;     // one wave hands out at most three packets per level
-constexpr uint32_t kShareSpinLimit = 1u << 18;
-
-
 // ---------------------------------------------------------------------------------------------
 // k_trace_general — recursiveRayTrace (src/render.cpp:27-147) with ALL its branches: the
 // transparency-only chain (:36-49), glossy reflections (:56-99) and the `transparency != 1`
@@ -785,14 +770,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         }
     } tl_end { a.sv.stamps, tl_begin, wave, lane, nullptr };
 #endif
-#ifdef RT_SHARE // tail work sharing ("Helpers" below): measured neutral to negative, compiled out by default
-    uint32_t* const sched = a.share.sched;
-#else
-    uint32_t* const sched = nullptr;
-#endif
-    if (sched && lane == 0)
-        sh_add(&sched[SH_STARTED0 + (wave & 63u) * SH_SLOT_STRIDE], 1u);
-    if (!sched && ballot(active) == 0)
+    if (ballot(active) == 0)
         return;
 
     LaneCounters lc;
@@ -811,8 +789,6 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     mg.refl.o = mk(0, 0, 0), mg.refl.d = mk(0, 0, 0);
     // merged traversals need every pixel lane below 32 (tiles of up to 32 pixels) and a fused launch
     mg.enabled = a.fused != 0u && a.merge_next != 0u && (ballot(active) >> 32) == 0ull;
-    for (;;) { // work units of this wave: its own tile, then (Helpers) packets of other waves
-    if (ballot(active) != 0)
     for (;; level++) {
     // Deeper levels issue first: a tile's path tree is a serial chain of levels, and the
     // launch ends when the longest chain does.
@@ -882,53 +858,6 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         // queue, no launch per level, and deep sparse levels overlap with everything else.
         if (smask == 0)
             break;
-        if (sched) { // Helpers are waiting: hand them all but the first part of this wave's rays
-            const uint32_t k = (uint32_t)__builtin_popcountll(smask);
-            uint32_t parts = 1, base = 0;
-            if (k >= 2u * kShareMinRays) {
-                if (lane == 0) {
-                    const uint32_t claim = sh_load(&sched[SH_CLAIM]), alloc = sh_load(&sched[SH_ALLOC]);
-                    if (claim > alloc && alloc + kShareMaxParts < a.share.queue_cap) {
-                        parts = claim - alloc + 1u;
-                        parts = parts < k / kShareMinRays ? parts : k / kShareMinRays;
-                        parts = parts < kShareMaxParts ? parts : kShareMaxParts;
-                        if (parts > 1u) {
-                            const uint32_t chunk = (k + parts - 1u) / parts;
-                            base = sh_add(&sched[SH_RAY_ALLOC], k - chunk);
-                            if (base + (k - chunk) > a.share.ray_cap)
-                                parts = 1u;
-                        }
-                    }
-                }
-                parts = uni(parts), base = uni(base);
-            }
-            if (parts > 1u) {
-                const uint32_t chunk = (k + parts - 1u) / parts;
-                const uint32_t rank = prefix_count(smask);
-                if (spawn && rank >= chunk) {
-                    float4* q = a.share.rays + 2 * (size_t)(base + rank - chunk);
-                    q[0] = make_float4(refl.o.x, refl.o.y, refl.o.z, refl.d.x);
-                    q[1] = make_float4(refl.d.y, refl.d.z, __uint_as_float(item), __uint_as_float(pixel));
-                }
-                // publish: everything this wave stored (rays, state, direct colours) before the descriptors
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) {
-                    const uint32_t n_packets = (k - chunk + chunk - 1u) / chunk;
-                    sh_add(&sched[SH_CREATED], n_packets);
-                    const uint32_t idx0 = sh_add(&sched[SH_ALLOC], n_packets);
-                    for (uint32_t pk = 0; pk < n_packets; pk++) {
-                        const uint32_t first = chunk * (pk + 1u);
-                        const uint32_t cnt = k - first < chunk ? k - first : chunk;
-                        const unsigned long long desc = (1ull << 63) | ((unsigned long long)(uint32_t)(level + 1) << 40)
-                            | ((unsigned long long)cnt << 32) | (unsigned long long)(base + first - chunk);
-                        if (idx0 + pk < a.share.queue_cap)
-                            __hip_atomic_store(&a.share.queue[idx0 + pk], desc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                spawn = spawn && rank < chunk;
-            }
-        }
         active = spawn;
         ray = refl;
         t = kFltMax;
@@ -954,85 +883,6 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         }
     }
     break;
-    }
-    // ---- Helpers ------------------------------------------------------------------------
-    // A fused launch ends with a few waves still walking their tiles' path trees while most
-    // of the chip is idle (tools/timeline.py). Once every workgroup of the launch has started
-    // (nobody else needs this wave's slot) a finished wave takes a ticket and waits for the
-    // packet with that number; waves that still have rays see tickets outstanding at their
-    // next level boundary and publish parts of their rays as packets. Descriptor words are
-    // written once, by one agent-scope atomic store, after an agent-scope release of the
-    // payload; the helper acquires before reading it. A wave leaves when no work is pending.
-    if (!sched)
-        return;
-    constexpr unsigned long long kExit = 1ull << 62;
-    if (lane == 0)
-        sh_add(&sched[SH_FINISHED0 + (wave & 63u) * SH_SLOT_STRIDE], 1u); // this unit is finished
-    // Has every workgroup of the launch started? (then nobody needs this wave's slot)
-    uint32_t all_started = uni(sh_load(&sched[SH_ALL_STARTED]));
-    if (!all_started && wave + 16384u >= a.share.n_groups) { // only late workgroups can be the first to see it
-        if (wave_sum(sh_load(&sched[SH_STARTED0 + lane * SH_SLOT_STRIDE])) >= a.share.n_groups) {
-            all_started = 1u;
-            if (lane == 0)
-                __hip_atomic_store(&sched[SH_ALL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (!all_started)
-        return;
-    // the wave that finishes the LAST unit releases every waiting helper
-    auto all_finished = [&]() {
-        const uint32_t fin = wave_sum(sh_load(&sched[SH_FINISHED0 + lane * SH_SLOT_STRIDE]));
-        return fin >= a.share.n_groups + uni(sh_load(&sched[SH_CREATED]));
-    };
-    if (all_finished()) {
-        const uint32_t claim = uni(sh_load(&sched[SH_CLAIM])), alloc = uni(sh_load(&sched[SH_ALLOC]));
-        for (uint32_t i = alloc + lane; i < claim && i < a.share.queue_cap; i += 64u)
-            __hip_atomic_store(&a.share.queue[i], kExit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    uint32_t ticket = 0;
-    if (lane == 0)
-        ticket = sh_add(&sched[SH_CLAIM], 1u);
-    ticket = uni(ticket);
-    if (ticket >= a.share.queue_cap)
-        return;
-    // Poll only this ticket's own word (one waiter per word). The finished counts are summed
-    // rarely, as a backstop for a helper that took its ticket while the last finisher was
-    // already handing out exits.
-    unsigned long long desc = 0;
-    for (uint32_t spins = 0;; spins++) {
-        desc = uni64(__hip_atomic_load(&a.share.queue[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (desc != 0)
-            break;
-        if ((spins & 63u) == 0u && all_finished())
-            break;
-        if (spins > kShareSpinLimit) { // never expected: report instead of hanging
-            if (lane == 0)
-                __hip_atomic_store(&sched[SH_ERROR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        const uint32_t naps = spins < 4u ? 1u : (spins < 16u ? 2u : 4u);
-        for (uint32_t i = 0; i < naps; i++)
-            __builtin_amdgcn_s_sleep(127);
-    }
-    if (desc == kExit)
-        desc = 0;
-    if (desc == 0)
-        return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const uint32_t cnt = (uint32_t)(desc >> 32) & 0xffu, base = (uint32_t)desc;
-    level = (int32_t)((desc >> 40) & 0xffu);
-    active = lane < cnt;
-    t = kFltMax;
-    if (active) {
-        const float4* q = a.share.rays + 2 * (size_t)(base + lane);
-        const float4 q0 = q[0], q1 = q[1];
-        ray.o = mk(q0.x, q0.y, q0.z);
-        ray.d = mk(q0.w, q1.x, q1.y);
-        item = __float_as_uint(q1.z), pixel = __float_as_uint(q1.w);
-    }
-    if (COUNT && active)
-        rc.closest = 1;
     }
 }
 
