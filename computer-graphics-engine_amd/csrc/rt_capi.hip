@@ -30,7 +30,7 @@ std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_prio { 0 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
+std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -418,7 +418,6 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     // fused_from = k: levels below k get a launch each (rays re-packed through the device
     // queue between them), level k's launch then runs all deeper levels inside its waves
     const int32_t fused_from = fused ? std::min(g_fused_from.load(), n_levels - 1) : n_levels;
-    a.prio_levels = g_prio.load() ? 1u : 0u;
     a.merge_next = g_merge_next.load() ? 1u : 0u;
     a.tile_cull = g_tile_cull.load() && !counters_dev ? 1u : 0u; // the counting pass traces every primary ray
     a.level_stride = (size_t)n_items * 3;
@@ -578,10 +577,6 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "fused") == 0) { // 1: all recursion levels in one launch (default); 0: one launch per level
         g_fused.store(value != 0);
-        return RT_OK;
-    }
-    if (name && strcmp(name, "prio") == 0) { // 1: deeper recursion levels get a higher wave priority (default)
-        g_prio.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "launch_rect") == 0) { // 1: launch only the tiles inside the scene's screen rectangle

@@ -53,7 +53,6 @@ struct LevelArgs {
     uint32_t min_waves;       // sparse levels: fewer rays per wave until this many waves are busy
     uint32_t fused;           // 1: the wave traces its own reflection rays, all levels in this launch
     size_t level_stride;      // floats between the `direct` planes of consecutive levels
-    uint32_t prio_levels;     // 1: s_setprio by recursion level (deeper = higher)
     uint32_t merge_next;      // 1: trace a level's first shadow rays together with the next level's reflection rays
     uint32_t tile_cull;       // 1: primary tiles that cannot reach the scene bounds skip the traversal
     RaySoA out;

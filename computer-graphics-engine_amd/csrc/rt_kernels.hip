@@ -790,18 +790,6 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     // merged traversals need every pixel lane below 32 (tiles of up to 32 pixels) and a fused launch
     mg.enabled = a.fused != 0u && a.merge_next != 0u && (ballot(active) >> 32) == 0ull;
     for (;; level++) {
-    // Deeper levels issue first: a tile's path tree is a serial chain of levels, and the
-    // launch ends when the longest chain does.
-    if (a.prio_levels) {
-        if (level <= 0)
-            __builtin_amdgcn_s_setprio(0);
-        else if (level == 1)
-            __builtin_amdgcn_s_setprio(1);
-        else if (level == 2)
-            __builtin_amdgcn_s_setprio(2);
-        else
-            __builtin_amdgcn_s_setprio(3);
-    }
     // ---- closest hit (bvh.intersect, render.cpp:31) — unless the previous level's merged
     //      traversal (MergeNext) already found it
     int32_t pos;
