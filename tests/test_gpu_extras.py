@@ -164,3 +164,26 @@ def test_recursion_variants_trace_batch(rt, oracle, abi, scenes):
     got = rt.trace_batch(bvh, rays, f, p)
     want, _ = oracle.trace_batch(ob, rays, f, p)
     assert_colors_close(got, want)
+
+
+@pytest.mark.parametrize("flags,params", [
+    (dict(enableRecursive=1), dict(depth=3)),
+    (dict(enableRecursive=1, enableMultipleRaysPerPixel=1), dict(depth=2, rays_per_pixel_side=2)),
+    (dict(enableRecursive=1, enableGlossyReflection=1), dict(depth=2, rays_per_reflection=2)),
+    (dict(enableTransparency=1, enableBloomEffect=1), dict(depth=2)),
+])
+def test_small_object_on_a_large_screen(rt, oracle, abi, scenes, monkey, flags, params):
+    """A distant object: only the tiles inside the scene's screen rectangle are launched
+    (host_launch_rect), the rest of the frame is filled by k_fold / k_resolve — for the plain path,
+    pixel samples, the general recursion kernel and the bloom filter alike. Also off-centre."""
+    data, bvh, ob = monkey
+    f = abi.Features.make(**{**BASE, **flags, "enableRecursive": flags.get("enableRecursive", 0)})
+    p = abi.RenderParams.make(**params)
+    W, H = 208, 120
+    fovy, aspect, _, _, rot = scenes.default_camera_args(W, H)
+    for look_at, dist in (((0.0, 0.0, 0.0), 9.0), ((1.6, -0.9, 0.0), 7.0)):
+        rgb = rt.render(bvh, rt.camera(fovy, aspect, look_at, dist, rot), f, p, W, H)
+        orgb, _, _, _ = oracle.render(ob, oracle.camera(fovy, aspect, look_at, dist, rot), f, p, W, H)
+        lit = np.isfinite(orgb).all(axis=2) & (orgb != 0).any(axis=2)
+        assert 20 < lit.sum() < W * H // 6, "the object must be small on the screen"
+        assert_colors_close(rgb, orgb)
