@@ -237,6 +237,41 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
 // (the shadow rays are traced by the whole wave).
 // GENERAL: also compiles the shadow query of enableTransparency (closest blocker's transparency) —
 // only k_trace_general needs it, the plain kernel stays one traversal instantiation smaller.
+// Position and colour of sample s of light L for the pixel with RNG key `pixel`
+// (point light; sampleSegmentLight, light.cpp:19-26; sampleParallelogramLight, light.cpp:30-45)
+RT_DEV void light_sample(const LightRec RT_CONST_AS* L, int32_t kind, const LevelArgs& a, uint32_t pixel, int32_t level,
+    uint32_t li, int32_t s, V3& lpos, V3& lcol)
+{
+    if (kind == RT_LIGHT_POINT) {
+        lpos = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
+        lcol = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
+    } else if (kind == RT_LIGHT_SEGMENT) {
+        const V3 e0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]), e1 = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
+        const V3 c0 = mk(L->v[2][0], L->v[2][1], L->v[2][2]), c1 = mk(L->v[3][0], L->v[3][1], L->v[3][2]);
+        const float r = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
+        const float weight = ((float)s + r) / (float)a.segment_n;
+        lpos = (e1 - e0) * weight + e0;
+        lcol = weight * c1 + (1 - weight) * c0;
+    } else {
+        const int32_t n = a.parallelogram_n;
+        const int32_t i = s / n, k = s - i * n;
+        const V3 v0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
+        const V3 e01 = mk(L->v[1][0], L->v[1][1], L->v[1][2]), e02 = mk(L->v[2][0], L->v[2][1], L->v[2][2]);
+        const V3 c0 = mk(L->v[3][0], L->v[3][1], L->v[3][2]), c1 = mk(L->v[4][0], L->v[4][1], L->v[4][2]);
+        const V3 c2 = mk(L->v[5][0], L->v[5][1], L->v[5][2]), c3 = mk(L->v[6][0], L->v[6][1], L->v[6][2]);
+        const float horRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
+        const float verRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 1u));
+        const float horWeight = ((float)i + horRandom) / (float)n;
+        const float verWeight = ((float)k + verRandom) / (float)n;
+        const V3 horVector = horWeight * e01;
+        const V3 verVector = verWeight * e02;
+        lpos = v0 + horVector + verVector;
+        const V3 bottomColor = horWeight * c1 + (1 - horWeight) * c0;
+        const V3 topColor = horWeight * c3 + (1 - horWeight) * c2;
+        lcol = verWeight * topColor + (1 - verWeight) * bottomColor;
+    }
+}
+
 // The next level's closest-hit query, traced TOGETHER with this level's first shadow query
 // (traverse<Q_MIXED>): pixel lanes (all < 32) carry their reflection ray in their own ray slot,
 // lane p + 32 carries pixel p's shadow ray. One traversal with twice the rays instead of two:
@@ -250,7 +285,10 @@ struct MergeNext {
     float t = kFltMax;
 };
 
-template <bool COUNT, bool GENERAL>
+// AREA: compiles the area-light (segment / parallelogram) code; the plain kernel without it is
+// what renders scenes lit by point lights only (the area-light code in the same kernel costs
+// the point-light path 2 % through register allocation alone).
+template <bool COUNT, bool GENERAL, bool AREA>
 RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int32_t pos, int32_t level, uint32_t pixel,
     const HitL& h, LaneCounters& lc, RayCounts& rc, WaveLds& wl, MergeNext* mg)
 {
@@ -264,45 +302,60 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
     if (flags & F_SHADING) {
         V3 result = mk(0.0f, 0.0f, 0.0f);
         const LightRec RT_CONST_AS* lights = (const LightRec RT_CONST_AS*)sv.lights;
+        // free lanes above the tile's pixels: 16-pixel tiles leave room for 4 shadow samples per
+        // traversal, 32-pixel tiles for 2
+        const uint64_t hit_mask = ballot(hit);
+        const uint32_t batch = (hit_mask >> 16) == 0ull ? 4u : ((hit_mask >> 32) == 0ull ? 2u : 1u);
         for (uint32_t li = 0; li < sv.n_lights; li++) {
             const LightRec RT_CONST_AS* L = lights + li;
             const int32_t kind = L->kind;
             const bool is_point = kind == RT_LIGHT_POINT;
-            if (!is_point && !(flags & F_SOFT_SHADOW))
+            if (!is_point && (!AREA || !(flags & F_SOFT_SHADOW)))
                 continue; // segment / parallelogram lights only contribute with soft shadows
             const bool trace_shadow = is_point ? (flags & F_HARD_SHADOW) != 0 : true;
             const int32_t n = a.parallelogram_n;
             const int32_t nsamp = is_point ? 1 : (kind == RT_LIGHT_SEGMENT ? a.segment_n : n * n);
             V3 acc = mk(0.0f, 0.0f, 0.0f);
-            for (int32_t s = 0; s < nsamp; s++) {
-                V3 lpos, lcol;
-                if (is_point) {
-                    lpos = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
-                    lcol = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
-                } else if (kind == RT_LIGHT_SEGMENT) { // sampleSegmentLight, light.cpp:19-26
-                    const V3 e0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]), e1 = mk(L->v[1][0], L->v[1][1], L->v[1][2]);
-                    const V3 c0 = mk(L->v[2][0], L->v[2][1], L->v[2][2]), c1 = mk(L->v[3][0], L->v[3][1], L->v[3][2]);
-                    const float r = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
-                    const float weight = ((float)s + r) / (float)a.segment_n;
-                    lpos = (e1 - e0) * weight + e0;
-                    lcol = weight * c1 + (1 - weight) * c0;
-                } else { // sampleParallelogramLight, light.cpp:30-45
-                    const int32_t i = s / n, k = s - i * n;
-                    const V3 v0 = mk(L->v[0][0], L->v[0][1], L->v[0][2]);
-                    const V3 e01 = mk(L->v[1][0], L->v[1][1], L->v[1][2]), e02 = mk(L->v[2][0], L->v[2][1], L->v[2][2]);
-                    const V3 c0 = mk(L->v[3][0], L->v[3][1], L->v[3][2]), c1 = mk(L->v[4][0], L->v[4][1], L->v[4][2]);
-                    const V3 c2 = mk(L->v[5][0], L->v[5][1], L->v[5][2]), c3 = mk(L->v[6][0], L->v[6][1], L->v[6][2]);
-                    const float horRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 0u));
-                    const float verRandom = rand01(rand31(a.seed, pixel, (uint32_t)level, li, (uint32_t)s, 1u));
-                    const float horWeight = ((float)i + horRandom) / (float)n;
-                    const float verWeight = ((float)k + verRandom) / (float)n;
-                    const V3 horVector = horWeight * e01;
-                    const V3 verVector = verWeight * e02;
-                    lpos = v0 + horVector + verVector;
-                    const V3 bottomColor = horWeight * c1 + (1 - horWeight) * c0;
-                    const V3 topColor = horWeight * c3 + (1 - horWeight) * c2;
-                    lcol = verWeight * topColor + (1 - verWeight) * bottomColor;
+            // Area lights: B samples per traversal. The tile's pixels sit in the low lanes; lane
+            // p + j * stride carries the shadow ray of pixel p's sample s0 + j, one any-hit traversal
+            // serves all of them, and the pixel lane adds the contributions in the reference's order.
+            int32_t s_begin = 0;
+            if (AREA && !GENERAL && !is_point && batch > 1u) {
+                const uint32_t lane = lane_id();
+                const uint32_t stride = 64u / batch, kk = lane / stride;
+                const int src = (int)(lane % stride);
+                RayL rs;
+                rs.o = mk(__shfl(ray.o.x, src, 64), __shfl(ray.o.y, src, 64), __shfl(ray.o.z, src, 64));
+                rs.d = mk(__shfl(ray.d.x, src, 64), __shfl(ray.d.y, src, 64), __shfl(ray.d.z, src, 64));
+                const float ts = __shfl(t, src, 64);
+                const uint32_t pix_s = (uint32_t)__shfl((int)pixel, src, 64);
+                const bool hit_s = __shfl((int)hit, src, 64) != 0;
+                for (int32_t s0 = 0; s0 < nsamp; s0 += (int32_t)batch) {
+                    const int32_t s_mine = s0 + (int32_t)kk;
+                    V3 lp, lcq;
+                    light_sample(L, kind, a, pix_s, level, li, s_mine < nsamp ? s_mine : 0, lp, lcq);
+                    const RayL sray = shadow_ray(rs, ts, lp);
+                    float st = 1.0f;
+                    int32_t spos;
+                    traverse<Q_ANY, COUNT>(sv, use_bvh, prune, hit_s && s_mine < nsamp, sray, st, spos, lc, wl);
+                    const int blocked = spos >= 0 ? 1 : 0;
+                    for (uint32_t j = 0; j < batch && s0 + (int32_t)j < nsamp; j++) {
+                        const float visibility = __shfl(blocked, (int)(lane % stride + j * stride), 64) ? 0.0f : 1.0f;
+                        V3 lpos, lcol;
+                        light_sample(L, kind, a, pixel, level, li, s0 + (int32_t)j, lpos, lcol);
+                        V3 color = mk(0.0f, 0.0f, 0.0f);
+                        if (hit)
+                            color = compute_shading(lpos, lcol, ray, t, h);
+                        acc = acc + color * visibility;
+                        if (COUNT && hit)
+                            rc.shadow++;
+                    }
                 }
+                s_begin = nsamp;
+            }
+            for (int32_t s = s_begin; s < nsamp; s++) {
+                V3 lpos, lcol;
+                light_sample(L, kind, a, pixel, level, li, s, lpos, lcol);
                 float visibility = 1.0f;
                 if (trace_shadow) { // testVisibilityLightSample, light.cpp:49-73
                     const RayL sray = shadow_ray(ray, t, lpos);
@@ -476,7 +529,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
             h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
             if (hit)
                 resolve_hit(sv, flags, ray, t, pos, h);
-            const V3 Lo0 = shade_hit<COUNT, true>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, nullptr);
+            const V3 Lo0 = shade_hit<COUNT, true, true>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, nullptr);
             if (COUNT && hit)
                 rc.hits = 1;
             if (COUNT)
@@ -689,7 +742,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool AREA>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const LevelArgs a)
 {
     const uint32_t lane = lane_id();
@@ -827,7 +880,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         spawn = compute_reflection_ray(ray, t, h, refl);
     mg.spawn = spawn, mg.refl = refl;
 
-    const V3 Lo = shade_hit<COUNT, false>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, &mg);
+    const V3 Lo = shade_hit<COUNT, false, AREA>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, &mg);
     if (hit) {
         float* d = a.direct + (size_t)(level - first_level) * a.level_stride + 3 * (size_t)item;
         d[0] = Lo.x, d[1] = Lo.y, d[2] = Lo.z;
@@ -1170,9 +1223,11 @@ void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
         return;
     const uint32_t grid = grid_for_waves(waves);
     if (count)
-        hipLaunchKernelGGL(k_trace_level<true>, dim3(grid), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((k_trace_level<true, true>), dim3(grid), dim3(kBlock), 0, s, a);
+    else if (a.area_lights)
+        hipLaunchKernelGGL((k_trace_level<false, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
     else
-        hipLaunchKernelGGL(k_trace_level<false>, dim3(grid), dim3(kBlock), g_lds_pad, s, a);
+        hipLaunchKernelGGL((k_trace_level<false, false>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
 }
 
 uint32_t trace_general_waves(const LevelArgs& a)
