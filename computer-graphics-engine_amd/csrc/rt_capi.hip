@@ -419,11 +419,12 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     // queue between them), level k's launch then runs all deeper levels inside its waves
     const int32_t fused_from = fused ? std::min(g_fused_from.load(), n_levels - 1) : n_levels;
     a.merge_next = g_merge_next.load() ? 1u : 0u;
-    a.area_lights = 0u;
+    bool area_lights = false;
     if (f.enableSoftShadow)
         for (const rt::LightRec& l : bvh->scene->host.lights)
             if (l.kind != RT_LIGHT_POINT)
-                a.area_lights = 1u;
+                area_lights = true;
+    a.lean = !area_lights && !f.enableNormalInterp && !f.enableTextureMapping && bvh->scene->host.spheres.empty() ? 1u : 0u;
     a.tile_cull = g_tile_cull.load() && !counters_dev ? 1u : 0u; // the counting pass traces every primary ray
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;

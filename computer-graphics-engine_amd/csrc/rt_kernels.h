@@ -55,7 +55,8 @@ struct LevelArgs {
     size_t level_stride;      // floats between the `direct` planes of consecutive levels
     uint32_t merge_next;      // 1: trace a level's first shadow rays together with the next level's reflection rays
     uint32_t tile_cull;       // 1: primary tiles that cannot reach the scene bounds skip the traversal
-    uint32_t area_lights;     // 1: soft shadows are on and the scene has segment / parallelogram lights
+    uint32_t lean;            // 1: point lights only (or soft shadows off), triangles only, no normal interpolation /
+                              //    textures: the lean kernel variant renders it
     RaySoA out;
     uint32_t* out_count;
     float* direct;   // this level's direct-light colours, n_items * 3

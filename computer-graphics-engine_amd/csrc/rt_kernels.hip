@@ -285,10 +285,10 @@ struct MergeNext {
     float t = kFltMax;
 };
 
-// AREA: compiles the area-light (segment / parallelogram) code; the plain kernel without it is
-// what renders scenes lit by point lights only (the area-light code in the same kernel costs
-// the point-light path 2 % through register allocation alone).
-template <bool COUNT, bool GENERAL, bool AREA>
+// LEAN: the kernel variant for the common plain case — point lights only (or soft shadows off),
+// triangles only, no normal interpolation, no textures; none of that code is compiled in (the
+// area-light code alone costs the point-light path 2 % through register allocation).
+template <bool COUNT, bool GENERAL, bool LEAN>
 RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int32_t pos, int32_t level, uint32_t pixel,
     const HitL& h, LaneCounters& lc, RayCounts& rc, WaveLds& wl, MergeNext* mg)
 {
@@ -310,7 +310,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
             const LightRec RT_CONST_AS* L = lights + li;
             const int32_t kind = L->kind;
             const bool is_point = kind == RT_LIGHT_POINT;
-            if (!is_point && (!AREA || !(flags & F_SOFT_SHADOW)))
+            if (!is_point && (LEAN || !(flags & F_SOFT_SHADOW)))
                 continue; // segment / parallelogram lights only contribute with soft shadows
             const bool trace_shadow = is_point ? (flags & F_HARD_SHADOW) != 0 : true;
             const int32_t n = a.parallelogram_n;
@@ -320,7 +320,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
             // p + j * stride carries the shadow ray of pixel p's sample s0 + j, one any-hit traversal
             // serves all of them, and the pixel lane adds the contributions in the reference's order.
             int32_t s_begin = 0;
-            if (AREA && !GENERAL && !is_point && batch > 1u) {
+            if (!LEAN && !GENERAL && !is_point && batch > 1u) {
                 const uint32_t lane = lane_id();
                 const uint32_t stride = 64u / batch, kk = lane / stride;
                 const int src = (int)(lane % stride);
@@ -337,7 +337,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                     const RayL sray = shadow_ray(rs, ts, lp);
                     float st = 1.0f;
                     int32_t spos;
-                    traverse<Q_ANY, COUNT>(sv, use_bvh, prune, hit_s && s_mine < nsamp, sray, st, spos, lc, wl);
+                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, hit_s && s_mine < nsamp, sray, st, spos, lc, wl);
                     const int blocked = spos >= 0 ? 1 : 0;
                     for (uint32_t j = 0; j < batch && s0 + (int32_t)j < nsamp; j++) {
                         const float visibility = __shfl(blocked, (int)(lane % stride + j * stride), 64) ? 0.0f : 1.0f;
@@ -380,13 +380,13 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                             tq = kFltMax;
                         }
                         int32_t pq;
-                        traverse<Q_MIXED, COUNT>(sv, use_bvh, prune, act, q, tq, pq, lc, wl);
+                        traverse<Q_MIXED, COUNT, LEAN>(sv, use_bvh, prune, act, q, tq, pq, lc, wl);
                         mg->pos = pq, mg->t = tq, mg->done = true;
                         spos = __shfl(pq, (int)(lane | 32u), 64);
                         if (spos >= 0)
                             visibility = 0.0f;
                     } else if (!GENERAL || !(flags & F_TRANSPARENCY)) {
-                        traverse<Q_ANY, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
+                        traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
                         if (spos >= 0)
                             visibility = 0.0f;
                     } else { // light.cpp:66-69: the CLOSEST blocker's material.transparency
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
             h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
             if (hit)
                 resolve_hit(sv, flags, ray, t, pos, h);
-            const V3 Lo0 = shade_hit<COUNT, true, true>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, nullptr);
+            const V3 Lo0 = shade_hit<COUNT, true, false>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, nullptr);
             if (COUNT && hit)
                 rc.hits = 1;
             if (COUNT)
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
     }
 }
 
-template <bool COUNT, bool AREA>
+template <bool COUNT, bool LEAN>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const LevelArgs a)
 {
     const uint32_t lane = lane_id();
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         t = mg.t;
         mg.done = false;
     } else {
-        traverse<Q_CLOSEST, COUNT>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
+        traverse<Q_CLOSEST, COUNT, LEAN>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
     }
     const bool hit = active && pos >= 0;
     if (active) {
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     h.normal = mk(0, 0, 1), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
     h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
     if (hit)
-        resolve_hit(sv, flags, ray, t, pos, h);
+        resolve_hit<LEAN>(sv, flags, ray, t, pos, h);
     if (COUNT && hit)
         rc.hits = 1;
 
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         spawn = compute_reflection_ray(ray, t, h, refl);
     mg.spawn = spawn, mg.refl = refl;
 
-    const V3 Lo = shade_hit<COUNT, false, AREA>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, &mg);
+    const V3 Lo = shade_hit<COUNT, false, LEAN>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, &mg);
     if (hit) {
         float* d = a.direct + (size_t)(level - first_level) * a.level_stride + 3 * (size_t)item;
         d[0] = Lo.x, d[1] = Lo.y, d[2] = Lo.z;
@@ -1223,8 +1223,8 @@ void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
         return;
     const uint32_t grid = grid_for_waves(waves);
     if (count)
-        hipLaunchKernelGGL((k_trace_level<true, true>), dim3(grid), dim3(kBlock), 0, s, a);
-    else if (a.area_lights)
+        hipLaunchKernelGGL((k_trace_level<true, false>), dim3(grid), dim3(kBlock), 0, s, a);
+    else if (a.lean)
         hipLaunchKernelGGL((k_trace_level<false, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
     else
         hipLaunchKernelGGL((k_trace_level<false, false>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);

@@ -89,6 +89,8 @@ RT_DEV float hit_transparency(const SceneView& sv, uint32_t flags, int32_t pos)
 
 // Hit attribute resolution — src/bounding_volume_hierarchy.cpp:365-426.
 // `pos` is the array index of the reported primitive; returns its prim id.
+// LEAN: triangles only, no normal interpolation, no textures (the lean kernel variant)
+template <bool LEAN = false>
 RT_DEV int32_t resolve_hit(const SceneView& sv, uint32_t flags, const RayL& ray, float t, int32_t pos, HitL& h)
 {
     const PrimRecord* rec = ((flags & F_ACCEL) ? sv.prims : sv.prims_flat) + pos;
@@ -97,14 +99,14 @@ RT_DEV int32_t resolve_hit(const SceneView& sv, uint32_t flags, const RayL& ray,
     const MaterialRec* m = sv.materials + (km & 0x7fffffffu);
     h.kd = ld3(m->kd), h.ks = ld3(m->ks);
     h.shininess = m->shininess, h.transparency = m->transparency, h.texture = m->texture;
-    if (km & 0x80000000u) { // sphere (:400-403, :421-423)
+    if (!LEAN && (km & 0x80000000u)) { // sphere (:400-403, :421-423)
         const V3 p = ray.o + ray.d * t;
         h.normal = normalize(p - ld3(rec->v0));
         return prim_id;
     }
     const bool interp = (flags & F_NORMAL_INTERP) != 0;
     const bool textured = (flags & F_TEXTURE) != 0 && h.texture >= 0;
-    if (!interp && !textured) {
+    if (LEAN || (!interp && !textured)) {
         h.normal = ld3(rec->n); // normalize(cross(v2 - v1, v3 - v1)) == the plane normal (:395-397)
         return prim_id;
     }

@@ -425,7 +425,9 @@ struct Walk {
 // `active` selects the lanes that carry a ray; ALL lanes of the wave must call.
 // use_bvh = features.enableAccelStructure; when false the whole array is one leaf
 // in the reference's own order (bvh.cpp:303-305; sv.leaf_flat).
-template <int MODE, bool COUNT>
+// NO_SPHERES: the caller knows the scene holds triangles only (lean kernel variant): the sphere
+// test is not compiled in.
+template <int MODE, bool COUNT, bool NO_SPHERES = false>
 RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active, const RayL& ray, float& t,
     int32_t& pos, LaneCounters& lc, WaveLds& L)
 {
@@ -445,7 +447,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     L.best[lane] = kNoHit;
     Walk<MODE, COUNT> w { sv, L, make_rsrc(use_bvh ? sv.leaf : sv.leaf_flat, sv.n_prims * 48u),
         make_rsrc(sv.nodes, sv.n_pairs * 64u), make_rsrc(sv.leaf_grouped, sv.n_groups * 4u * 48u),
-        make_rsrc(sv.groups, sv.n_groups * 32u), sv.prune_ok == 0u, lc, lane, prune, 0u, ray, inv, lane };
+        make_rsrc(sv.groups, sv.n_groups * 32u), !NO_SPHERES && sv.prune_ok == 0u, lc, lane, prune, 0u, ray, inv, lane };
 #ifdef RT_STAMPS
     const unsigned long long stamp_begin = clock64();
 #endif
@@ -462,7 +464,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
         if (!any_hit_slot<MODE>(lane)) { // the reported primitive's own t, with its exact bits (-0.0f included)
             const PrimRecord rec = (use_bvh ? sv.prims : sv.prims_flat)[pos];
             float tt;
-            if (rec.kind_mat & 0x80000000u)
+            if (!NO_SPHERES && (rec.kind_mat & 0x80000000u))
                 sphere_candidate(rec, ray, t, tt);
             else
                 tt = tri_plane_t(rec, ray);
