@@ -61,22 +61,39 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="one rank only: successive frames on alternating HIP streams, so that the tail of frame k "
-                         "(a few long path trees) overlaps the start of frame k + 1; 1 = strictly one frame at a time")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="successive frames on alternating HIP streams, so that the tail of frame k (a few long "
+                         "path trees) overlaps the start of the next frames; default 2 on one GPU and 8 on several "
+                         "(a rank's share of a frame is small, so more of them fit the chip at once); "
+                         "1 = strictly one frame at a time")
     ap.add_argument("--tile-log", type=int, nargs=2, default=None, metavar=("W", "H"),
                     help="primary tile = 2^W x 2^H pixels per wave (default: 2 3 with frames in flight, else the "
                          "library's latency setting 1 3)")
+    ap.add_argument("--exchange-batch", type=int, default=None,
+                    help="several GPUs: successive frames that share one all-gather + one de-interleave launch "
+                         "(default 8); every frame is still rendered and assembled")
+    ap.add_argument("--exchange-always", action="store_true",
+                    help="one GPU: take the strips + RCCL exchange path with a one-rank group (what the N > 1 run "
+                         "adds on top of the render: packed strips, all-gather, de-interleave), for measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not bracket trace kernels with HIP events during the timed steps")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.frames_in_flight is None:
+        args.frames_in_flight = 2 if world == 1 else 8
+    if args.exchange_batch is None:
+        args.exchange_batch = 1 if world == 1 else 8
+    # HIP runtime setting, read when the runtime starts: how many hardware queues the streams of this
+    # process are dealt over (default 4) = how many of the frames in flight really run side by side
+    # (tools/queue_bench.hip); + the exchange stream, torch's RCCL stream and the null stream
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.frames_in_flight + 4)))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -86,7 +103,7 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.exchange_always:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if rehearsal:
@@ -117,14 +134,15 @@ def main():
     if args.tile_log:
         rt.set_option("tile_wlog", args.tile_log[0])
         rt.set_option("tile_hlog", args.tile_log[1])
-    elif world == 1 and args.frames_in_flight > 1:
+    elif args.frames_in_flight > 1:
         # Throughput setting of the library's tuning knobs: 4x8-pixel primary tiles (32 rays per wave; with the
         # merged traversals all 64 ray slots are used) do 30 % less instruction work than the latency setting
         # (2x8) but end in longer path-tree tails — which the next frame in flight covers. Results are identical.
         rt.set_option("tile_wlog", 2)
         rt.set_option("tile_hlog", 3)
     renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, rank, world, strip_rows=STRIP_ROWS,
-                                      frames_in_flight=args.frames_in_flight)
+                                      frames_in_flight=args.frames_in_flight, exchange_always=args.exchange_always,
+                                      exchange_batch=args.exchange_batch)
 
     # ---- untimed counting pass: rays and tests of THIS rank's strips ------------
     cnt = renderer.count_rays(stream)
@@ -138,7 +156,7 @@ def main():
     # ---- warmup ----------------------------------------------------------------
     for _ in range(args.warmup):
         renderer.step(stream)
-    torch.cuda.synchronize()
+    renderer.finish()     # nothing of the warmup (a partial exchange batch) is left for the timed region
 
     # ---- timed steps -----------------------------------------------------------
     use_events = not args.no_profile_events
@@ -217,14 +235,15 @@ def main():
                        "rays_reflect": total["rays_reflect"], "box_tests": total["box_tests"],
                        "tri_tests": total["tri_tests"], "group_tests": total.get("group_tests", 0), "node_fetches": total["node_fetches"],
                        "tri_fetches": total["tri_fetches"], "algorithmic_bytes_per_frame": ab["frame"],
-                       "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather(overlapped)" if world > 1 else "")
+                       "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather(overlapped" + (f",{renderer.batch}-frames-each)" if renderer.batch > 1 else ")")
+                                                              if renderer.sharded else "")
                        + (f"+{renderer.flight}-frames-in-flight" if renderer.flight > 1 else "")
                        + ("+REHEARSAL-gloo-one-device" if rehearsal else ""),
                        "device": devname, "bvh_build_s": round(build_s, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.exchange_always:
         dist.barrier()
         dist.destroy_process_group()
 

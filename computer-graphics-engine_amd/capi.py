@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_last_error", "rt_device_info", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
-    "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips",
+    "rt_render_device", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
     "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
     "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp", "rt_bloom_device",
 ]
@@ -140,6 +140,8 @@ class Library:
                                          C.POINTER(abi.Counters)]
         c.rt_deinterleave_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_void_p]
+        c.rt_deinterleave_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_void_p]
         c.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
         c.rt_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         c.rt_set_option.argtypes = [C.c_char_p, C.c_int]
@@ -294,6 +296,12 @@ class Library:
                             stream: int = 0):
         self._check(self.c.rt_deinterleave_strips(C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), width, height,
                                                   strip_rows, n_ranks, C.c_void_p(stream) if stream else None))
+
+    def deinterleave_frames(self, gathered_ptr: int, frames_ptr: int, width, height, strip_rows, n_ranks, n_frames,
+                            batch_frames, stream: int = 0):
+        self._check(self.c.rt_deinterleave_frames(C.c_void_p(gathered_ptr), C.c_void_p(frames_ptr), width, height,
+                                                  strip_rows, n_ranks, n_frames, batch_frames,
+                                                  C.c_void_p(stream) if stream else None))
 
     def profile_enable(self, bvh: Bvh, enable: bool):
         self._check(self.c.rt_profile_enable(bvh.handle, 1 if enable else 0))

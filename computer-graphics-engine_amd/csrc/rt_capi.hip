@@ -1146,7 +1146,21 @@ int rt_deinterleave_strips(const float* gathered_dev, float* frame_dev, int32_t 
 {
     if (!gathered_dev || !frame_dev || width <= 0 || height <= 0 || strip_rows <= 0 || n_ranks <= 0)
         return fail(RT_ERR_INVALID, "rt_deinterleave_strips: bad argument");
-    rt::launch_deinterleave(gathered_dev, frame_dev, width, height, strip_rows, n_ranks, (hipStream_t)hip_stream);
+    rt::launch_deinterleave(gathered_dev, frame_dev, width, height, strip_rows, n_ranks, 1, 1, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_deinterleave_frames(const float* gathered_dev, float* frames_dev, int32_t width, int32_t height,
+    int32_t strip_rows, int32_t n_ranks, int32_t n_frames, int32_t batch_frames, void* hip_stream)
+{
+    if (!gathered_dev || !frames_dev || width <= 0 || height <= 0 || strip_rows <= 0 || n_ranks <= 0 || n_frames <= 0
+        || batch_frames < n_frames)
+        return fail(RT_ERR_INVALID, "rt_deinterleave_frames: bad argument");
+    if ((uint64_t)width * 3 * (uint64_t)height * (uint64_t)n_frames / 256 >= 0x7fffffffull)
+        return fail(RT_ERR_INVALID, "rt_deinterleave_frames: too many pixels for one launch");
+    rt::launch_deinterleave(gathered_dev, frames_dev, width, height, strip_rows, n_ranks, n_frames, batch_frames,
+        (hipStream_t)hip_stream);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

@@ -136,7 +136,7 @@ void launch_bloom(const BloomArgs& a, hipStream_t s);
 void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s);
 void launch_div_check(uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t per_thread, unsigned long long* out,
     hipStream_t s);
-void launch_deinterleave(const float* gathered, float* frame, int32_t width, int32_t height, int32_t strip_rows,
-    int32_t n_ranks, hipStream_t s);
+void launch_deinterleave(const float* gathered, float* frames, int32_t width, int32_t height, int32_t strip_rows,
+    int32_t n_ranks, int32_t n_frames, int32_t batch, hipStream_t s);
 
 } // namespace rt

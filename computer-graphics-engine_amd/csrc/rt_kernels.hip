@@ -1109,22 +1109,32 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const IntersectArgs a)
         flush_counters(a.counters, lc, rc, 0, lane);
 }
 
-// gathered: n_ranks blocks of rows_max*W*3 floats; strip s (strip_rows image rows)
-// was rendered by rank s % n_ranks as its local strip s / n_ranks.
-__global__ __launch_bounds__(256) void k_deinterleave(const float* __restrict__ gathered, float* __restrict__ frame,
-    int32_t width, int32_t height, int32_t strip_rows, int32_t n_ranks, int32_t rows_max)
+// gathered: n_ranks blocks of batch frames of rows_max*W*3 floats; strip s (strip_rows image rows) of
+// every frame was rendered by rank s % n_ranks as its local strip s / n_ranks. The first n_frames
+// frames of the batch are written, row-flipped, to frames[n_frames][H][W][3]. One thread moves VEC
+// floats of a row (VEC = 4 when a row is a whole number of float4s and the pointers are aligned).
+template <int VEC>
+__global__ __launch_bounds__(256) void k_deinterleave(const float* __restrict__ gathered, float* __restrict__ frames,
+    int32_t width, int32_t height, int32_t strip_rows, int32_t n_ranks, int32_t rows_max, int32_t n_frames,
+    int32_t batch)
 {
-    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x; // (y, x)
-    if (idx >= (size_t)width * height)
+    const size_t row_units = (size_t)width * 3 / VEC;
+    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x; // (frame, y, unit)
+    if (idx >= row_units * height * n_frames)
         return;
-    const int32_t y = (int32_t)(idx / (size_t)width);
-    const int32_t x = (int32_t)(idx - (size_t)y * width);
+    const int32_t fy = (int32_t)(idx / row_units);
+    const size_t u = idx - (size_t)fy * row_units;
+    const int32_t b = fy / height;
+    const int32_t y = fy - b * height;
     const int32_t strip = y / strip_rows;
     const int32_t rank = strip % n_ranks;
     const int32_t lrow = (strip / n_ranks) * strip_rows + (y - strip * strip_rows);
-    const float* src = gathered + ((size_t)rank * rows_max + lrow) * (size_t)width * 3 + 3 * (size_t)x;
-    float* dst = frame + ((size_t)(height - 1 - y) * width + x) * 3;
-    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2];
+    const float* src = gathered + (((size_t)rank * batch + b) * rows_max + lrow) * (size_t)width * 3 + VEC * u;
+    float* dst = frames + ((size_t)b * height + (height - 1 - y)) * (size_t)width * 3 + VEC * u;
+    if (VEC == 4)
+        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+    else
+        dst[0] = src[0];
 }
 
 // rt_debug_div_check: div_by_ray(n, d, RN(1/d)) against the device's own n / d on
@@ -1288,14 +1298,20 @@ void launch_div_check(uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t pe
     hipLaunchKernelGGL(k_div_check, dim3(blocks), dim3(256), 0, s, seed, mode, per_thread, out);
 }
 
-void launch_deinterleave(const float* gathered, float* frame, int32_t width, int32_t height, int32_t strip_rows,
-    int32_t n_ranks, hipStream_t s)
+void launch_deinterleave(const float* gathered, float* frames, int32_t width, int32_t height, int32_t strip_rows,
+    int32_t n_ranks, int32_t n_frames, int32_t batch, hipStream_t s)
 {
     const int32_t n_strips = (height + strip_rows - 1) / strip_rows;
     const int32_t rows_max = ((n_strips + n_ranks - 1) / n_ranks) * strip_rows;
-    const size_t n = (size_t)width * height;
-    hipLaunchKernelGGL(k_deinterleave, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, gathered, frame, width,
-        height, strip_rows, n_ranks, rows_max);
+    const bool vec = (width * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(gathered) & 15) == 0
+        && (reinterpret_cast<uintptr_t>(frames) & 15) == 0;
+    const size_t n = (size_t)width * 3 / (vec ? 4 : 1) * height * n_frames;
+    if (vec)
+        hipLaunchKernelGGL(k_deinterleave<4>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, gathered, frames,
+            width, height, strip_rows, n_ranks, rows_max, n_frames, batch);
+    else
+        hipLaunchKernelGGL(k_deinterleave<1>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, gathered, frames,
+            width, height, strip_rows, n_ranks, rows_max, n_frames, batch);
 }
 
 } // namespace rt

@@ -62,17 +62,58 @@ def gather_strips(gathered, local):
         dist.all_gather_into_tensor(gathered, local)
 
 
+def new_streams(n: int, high_priority: bool = False):
+    """n HIP streams created HERE, one after the other (hipStreamCreateWithFlags through the HIP runtime
+    torch already loaded), wrapped for torch. The runtime deals its hardware queues round-robin in creation
+    order (tools/queue_bench.hip), so consecutive streams of one call run side by side — streams taken from
+    torch's pool of 32 may share a queue. At most GPU_MAX_HW_QUEUES (HIP runtime setting, default 4) kernels
+    of a process run concurrently; bench.py raises it before the runtime starts."""
+    import ctypes
+
+    import torch
+
+    # the copy of the HIP runtime this process already runs on (torch brings its own), never a second one
+    loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln]
+    if not loaded:
+        raise RuntimeError("the HIP runtime is not loaded: no GPU build of torch in this process")
+    hip = ctypes.CDLL(loaded[0])
+    hip.hipStreamCreateWithPriority.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.c_int]
+    least, greatest = ctypes.c_int(), ctypes.c_int()
+    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+        raise RuntimeError("hipDeviceGetStreamPriorityRange failed")
+    out = []
+    for _ in range(n):
+        h = ctypes.c_void_p()
+        # high priority = numerically lowest; the exchange stream takes it so that its short kernels are
+        # dispatched ahead of the render workgroups of the frames in flight
+        err = hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, greatest.value if high_priority else 0)  # 1 = hipStreamNonBlocking
+        if err != 0:
+            raise RuntimeError(f"hipStreamCreateWithPriority failed: {err}")
+        out.append(torch.cuda.ExternalStream(h.value))
+    return out
+
+
 class StripRenderer:
     """One rank's share of a frame + the gather. `step()` enqueues a whole frame
     without host synchronisation; `frame` holds the newest assembled frame once the
     device is synchronised (`finish()`)."""
 
     def __init__(self, rt, bvh, cam, features, params, width, height, rank=0, world=1, strip_rows=8,
-                 overlap=True, frames_in_flight=1):
-        """frames_in_flight > 1 (one rank only): successive frames go to alternating HIP streams, each
-        with its own frame buffer and library scratch, so the tail of frame k — a few long path trees
-        on an otherwise idle chip — overlaps the start of frame k + 1. Every frame is rendered in
-        full; `frame` is the newest one after finish()."""
+                 overlap=True, frames_in_flight=1, exchange_always=False,
+                 exchange_batch=1):
+        """frames_in_flight > 1: successive frames go to alternating HIP streams, each with its own
+        buffers and library scratch, so the tail of frame k — a few long path trees on an otherwise
+        idle chip — overlaps the start of the next frames (with several ranks: the rank's strips of
+        the next frames; the smaller the share, the more frames it takes to fill the chip). Every
+        frame is rendered in full; `frame` is the newest one after finish().
+        exchange_batch > 1 (several ranks): that many successive frames share ONE all-gather and one
+        de-interleave launch (rt_deinterleave_frames). At 8 ranks a share of a frame renders in well
+        under 0.1 ms while an exchange — short kernels that must find room on a chip full of render
+        waves — takes longer than that; the exchanges of successive frames cannot overlap each other
+        (one communicator, one order), so they are made fewer. Every frame is still rendered,
+        exchanged and assembled; finish() flushes a partial batch.
+        exchange_always: take the strips + exchange path with ONE rank too (the all-gather of a
+        one-rank group) — how the GPU tests drive the RCCL branch on a one-GPU box."""
         import torch
 
         self.rt, self.bvh, self.cam, self.f, self.p = rt, bvh, cam, features, params
@@ -80,43 +121,60 @@ class StripRenderer:
         self.rows = strip_rows_of_rank(height, strip_rows, rank, world)
         self.frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
         self.counters = torch.zeros(16, dtype=torch.int64, device="cuda")
-        self.overlap = overlap and world > 1
+        self.sharded = world > 1 or exchange_always
+        self.overlap = overlap and self.sharded
         self.k = 0
-        self.flight = max(1, int(frames_in_flight)) if world == 1 else 1
+        self.flight = max(1, int(frames_in_flight)) if (not self.sharded or self.overlap) else 1
         if self.flight > 1:
-            self.streams = [torch.cuda.Stream() for _ in range(self.flight)]
+            self.streams = new_streams(self.flight)
+            self.started = [False] * self.flight
+        if not self.sharded and self.flight > 1:
             self.frames = [self.frame] + [torch.zeros_like(self.frame) for _ in range(self.flight - 1)]
         # renderBloomFilter works on the WHOLE frame (render.cpp:326-328): with several ranks the
         # strips are rendered without it and every rank filters its assembled copy of the frame
-        self.bloom = bool(features.enableBloomEffect) and world > 1
+        self.bloom = bool(features.enableBloomEffect) and self.sharded
         self.f_strips = features
         if self.bloom:
             self.f_strips = type(features).from_buffer_copy(bytes(features))
             self.f_strips.enableBloomEffect = 0
-        if world > 1:
+        self.batch = max(1, int(exchange_batch)) if self.overlap else 1
+        if self.sharded:
             rmax = rows_max(height, strip_rows, world)
-            nbuf = 2 if self.overlap else 1
-            self.local = [torch.zeros((rmax, width, 3), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-            self.gathered = [torch.zeros((world, rmax, width, 3), dtype=torch.float32, device="cuda")
+            B = self.batch
+            # batch buffers: those the frames in flight are rendering into + one in exchange + slack
+            nbuf = (-(-self.flight // B) + 3) if self.overlap else 1
+            self.local = [torch.zeros((B, rmax, width, 3), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+            self.gathered = [torch.zeros((world, B, rmax, width, 3), dtype=torch.float32, device="cuda")
                              for _ in range(nbuf)]
             if self.overlap:
-                self.comm_stream = torch.cuda.Stream()
-                self.rendered = [torch.cuda.Event() for _ in range(nbuf)]   # buffer i holds a finished render
-                self.consumed = [torch.cuda.Event() for _ in range(nbuf)]   # buffer i's exchange has read it
+                self.out = [torch.zeros((B, height, width, 3), dtype=torch.float32, device="cuda")
+                            for _ in range(nbuf)]
+                self.comm_stream = new_streams(1, high_priority=True)[0]
+                # rendered[i][b]: frame b of batch buffer i is rendered; consumed[i]: its exchange has read it
+                self.rendered = [[torch.cuda.Event() for _ in range(B)] for _ in range(nbuf)]
+                self.consumed = [torch.cuda.Event() for _ in range(nbuf)]
                 self.used = [False] * nbuf
+
+    def _render_stream(self, j):
+        """Render stream j of the frames in flight; its first use waits for whatever set the scene up."""
+        import torch
+
+        s = self.streams[j]
+        if not self.started[j]:
+            s.wait_stream(torch.cuda.current_stream())
+            self.started[j] = True
+        return s
 
     def step(self, stream: int = 0):
         """Render this rank's strips of one frame on `stream` (a raw hipStream_t, the
         current torch stream) and exchange them."""
         import torch
 
-        if self.world == 1:
+        if not self.sharded:
             if self.flight > 1:
                 j = self.k % self.flight
                 self.k += 1
-                s = self.streams[j]
-                if self.k <= self.flight:
-                    s.wait_stream(torch.cuda.current_stream())  # whatever set the scene up has finished
+                s = self._render_stream(j)
                 self.frame = self.frames[j]
                 self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
                                       stream=s.cuda_stream)
@@ -124,34 +182,58 @@ class StripRenderer:
             self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
                                   stream=stream)
             return
-        i = self.k % len(self.local)
-        self.k += 1
-        cur = torch.cuda.current_stream()
-        if self.overlap and self.used[i]:
-            cur.wait_event(self.consumed[i])  # the exchange two frames ago must have read this buffer
-        self.rt.render_device(self.bvh, self.cam, self.f_strips, self.p, self.W, self.H, self.local[i].data_ptr(),
-                              rows=self.rows, packed=True, stream=stream)
         if not self.overlap:
-            gather_strips(self.gathered[i], self.local[i])
-            self.rt.deinterleave_strips(self.gathered[i].data_ptr(), self.frame.data_ptr(), self.W, self.H,
+            self.rt.render_device(self.bvh, self.cam, self.f_strips, self.p, self.W, self.H, self.local[0].data_ptr(),
+                                  rows=self.rows, packed=True, stream=stream)
+            gather_strips(self.gathered[0], self.local[0])
+            self.rt.deinterleave_strips(self.gathered[0].data_ptr(), self.frame.data_ptr(), self.W, self.H,
                                         self.strip_rows, self.world, stream=stream)
             if self.bloom:
                 self.rt.bloom_device(self.frame.data_ptr(), self.W, self.H, self.p, stream=stream)
             return
-        self.rendered[i].record(cur)
-        with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(self.rendered[i])
-            gather_strips(self.gathered[i], self.local[i])
-            self.rt.deinterleave_strips(self.gathered[i].data_ptr(), self.frame.data_ptr(), self.W, self.H,
-                                        self.strip_rows, self.world, stream=self.comm_stream.cuda_stream)
-            if self.bloom:
-                self.rt.bloom_device(self.frame.data_ptr(), self.W, self.H, self.p, stream=self.comm_stream.cuda_stream)
-            self.consumed[i].record(self.comm_stream)
-        self.used[i] = True
+        # frames in flight: frame k renders on stream k % flight, so the tail of one rank's share (a
+        # few long path trees) overlaps the shares of the next frames; the exchanges follow in frame
+        # order on the one exchange stream (every rank issues them in the same order)
+        q, b = divmod(self.k, self.batch)
+        i = q % len(self.local)
+        j = self.k % self.flight
+        self.k += 1
+        cur = self._render_stream(j) if self.flight > 1 else torch.cuda.current_stream()
+        raw = cur.cuda_stream if self.flight > 1 else stream
+        if self.used[i]:
+            cur.wait_event(self.consumed[i])  # the exchange that read this buffer last must be over
+        self.rt.render_device(self.bvh, self.cam, self.f_strips, self.p, self.W, self.H,
+                              self.local[i][b].data_ptr(), rows=self.rows, packed=True, stream=raw)
+        self.rendered[i][b].record(cur)
+        if b == self.batch - 1:
+            self._exchange(i, self.batch)
 
-    def finish(self):
+    def _exchange(self, i, n):
+        """The exchange of batch buffer i, whose first n frames are rendered (or being rendered)."""
         import torch
 
+        with torch.cuda.stream(self.comm_stream):
+            for e in self.rendered[i][:n]:
+                self.comm_stream.wait_event(e)
+            gather_strips(self.gathered[i], self.local[i])
+            raw = self.comm_stream.cuda_stream
+            self.rt.deinterleave_frames(self.gathered[i].data_ptr(), self.out[i].data_ptr(), self.W, self.H,
+                                        self.strip_rows, self.world, n, self.batch, stream=raw)
+            if self.bloom:
+                for b in range(n):
+                    self.rt.bloom_device(self.out[i][b].data_ptr(), self.W, self.H, self.p, stream=raw)
+            self.consumed[i].record(self.comm_stream)
+        self.used[i] = True
+        self.frame = self.out[i][n - 1]
+
+    def finish(self):
+        """Flush a partial exchange batch and wait for the device."""
+        import torch
+
+        if self.sharded and self.overlap and self.k % self.batch:
+            n = self.k % self.batch
+            self._exchange((self.k // self.batch) % len(self.local), n)
+            self.k += self.batch - n      # the next frame opens a new batch
         torch.cuda.synchronize()
 
     def launch_streams(self, stream: int = 0):
@@ -164,7 +246,7 @@ class StripRenderer:
 
         abi = __import__("importlib").import_module("computer-graphics-engine_amd.abi")
         self.counters.zero_()
-        if self.world == 1:
+        if not self.sharded:
             self.rt.render_device(self.bvh, self.cam, self.f, self.p, self.W, self.H, self.frame.data_ptr(),
                                   counters_ptr=self.counters.data_ptr(), stream=stream)
         else:

@@ -330,6 +330,14 @@ int rt_debug_div_check(uint32_t seed, uint32_t mode, uint64_t n_samples, uint64_
 int rt_deinterleave_strips(const float* gathered_dev, float* frame_dev, int32_t width, int32_t height,
                            int32_t strip_rows, int32_t n_ranks, void* hip_stream);
 
+/* -- The same for a BATCH of frames exchanged in one all-gather (a rank's share of a frame is small at
+ *    8 ranks; several frames per exchange keep the exchange off the critical path): gathered_dev holds
+ *    n_ranks blocks of batch_frames frames of rows_per_rank_max*W*3 floats; the first n_frames of them
+ *    are written to frames_dev[n_frames][H][W][3], each row-flipped as above. One launch. ------------- */
+int rt_deinterleave_frames(const float* gathered_dev, float* frames_dev, int32_t width, int32_t height,
+                           int32_t strip_rows, int32_t n_ranks, int32_t n_frames, int32_t batch_frames,
+                           void* hip_stream);
+
 /* The area-light RNG (replaces rand(), src/light.cpp:21,32-33): 31-bit value
  * for (seed, pixel id, recursion level, light index, sample index, dim). */
 uint32_t rt_rand31(uint32_t seed, uint32_t pixel, uint32_t level, uint32_t light, uint32_t sample,
