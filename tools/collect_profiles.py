@@ -19,7 +19,7 @@ ks = newest(str(src / "stats" / "*" / "*_kernel_stats.csv"))
 shutil.copy(ks, dst / f"{tag}_rocprofv3_kernel_stats.csv")
 # per-level launch durations from the kernel trace (last 20 frames)
 rows = list(csv.DictReader(open(newest(str(src / "stats" / "*" / "*_kernel_trace.csv")))))
-tr = [r for r in rows if "k_trace_level<false>" in r["Kernel_Name"]]
+tr = [r for r in rows if "k_trace_level<false" in r["Kernel_Name"]]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
 bench = json.loads(open(src / "bench_default.json").read().strip().splitlines()[-1])
 LPF = max(1, int(round(bench["roofline"]["launches_per_frame"])))  # k_trace_level launches per frame (1 = fused)
@@ -28,7 +28,7 @@ pm = {}
 for f in sorted(newest(str(pd / "*" / "*_counter_collection.csv")) for pd in (src / "pmc").iterdir() if pd.is_dir()):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
-        if "k_trace_level<false>" in r["Kernel_Name"]:
+        if "k_trace_level<false" in r["Kernel_Name"]:
             per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     for c, d in per.items():
         ids = sorted(d)
