@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
             continue;
         int32_t op = active ? 1 : 0; // 0 none, 1 trace + shade (a recursiveRayTrace invocation), 2 probe
         int32_t rayDepth = a.depth, sp = 0;
-        uint32_t draws = 0;
+        uint32_t draws = 0, equiv_extra = 0;
         V3 result = mk(0.0f, 0.0f, 0.0f);
         for (;;) {
             const bool want = op != 0;
@@ -712,7 +712,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
                         fv.Lo = fv.Lo + val;
                         stage = GS_C2;
                     } else {
-                        val = fv.transp * val + (1 - fv.transp) * fv.Lo; // :123 (the intersect of :125-127 has no effect)
+                        val = fv.transp * val + (1 - fv.transp) * fv.Lo; // :123
+                        // the intersect of :125-127 has no effect and is not performed: counted as a
+                        // reference-equivalent ray only
+                        if (COUNT)
+                            equiv_extra++;
                         stage = GS_RET;
                     }
                     break;
@@ -733,6 +737,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
                     }
                 }
             }
+        }
+        if (COUNT) {
+            const uint32_t extra = wave_sum(equiv_extra);
+            if (lane == 0 && extra)
+                atomicAdd((unsigned long long*)&a.counters->rays_ref_equiv, (unsigned long long)extra);
         }
         if (active) { // one "level" holding the finished colour: k_fold adds vec3(0) and divides by 1
             a.state[item] = 1u;
