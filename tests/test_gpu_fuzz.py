@@ -96,6 +96,8 @@ def make_flags(rng, scene):
     p = dict(depth=int(rng.integers(0, 6)), parallelogram_n=int(rng.integers(1, 4)), segment_n=int(rng.integers(1, 5)),
              seed=int(rng.integers(0, 1 << 30)), rays_per_pixel_side=int(rng.integers(1, 3)), samples_dof=int(rng.integers(1, 3)),
              rays_per_reflection=int(rng.integers(1, 3)), bloom_threshold=float(rng.uniform(0.05, 0.6)))
+    if not f["enableAccelStructure"] and scene.n_triangles > 2000:
+        p["depth"] = min(p["depth"], 2)   # brute force x path trees: minutes of oracle time per case otherwise
     return f, p
 
 
@@ -146,3 +148,112 @@ def test_random_scenes_match_oracle(rt, oracle, abi):
         if case % 50 == 49:
             print(f"... {case + 1} cases, {len(bad)} bad, {time.time() - t_start:.0f} s", flush=True)
     assert not bad, f"{len(bad)} of {n_cases} random cases differ:\n" + "\n".join(bad[:10])
+
+
+def adversarial_rays(abi, rng, scene, n):
+    """Rays that aim at the special cases of the slab / triangle / sphere tests: origins exactly ON vertices and on
+    the coordinates of box faces, directions with exact zeros (the FLT_MIN / FLT_MAX slab quirk), directions along
+    triangle edges, denormal and huge components, zero and negative limits, infinities and NaNs."""
+    rays = np.zeros(n, abi.RAY_DTYPE)
+    verts = np.concatenate([m.positions for m in scene.meshes])
+    o = (rng.normal(size=(n, 3)) * 2).astype(np.float32)
+    tgt = verts[rng.integers(0, len(verts), n)] + (rng.normal(size=(n, 3)) * 0.05).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    kind = rng.integers(0, 12, n)
+    sel = kind == 1                                    # origin exactly on a vertex
+    o[sel] = verts[rng.integers(0, len(verts), sel.sum())]
+    sel = kind == 2                                    # one origin coordinate equal to a vertex coordinate (a box face)
+    ax = rng.integers(0, 3, n)
+    o[sel, ax[sel]] = verts[rng.integers(0, len(verts), sel.sum()), ax[sel]]
+    sel = kind == 3                                    # aimed exactly at a vertex
+    d[sel] = verts[rng.integers(0, len(verts), sel.sum())] - o[sel]
+    sel = kind == 4                                    # one zero component
+    d[sel, ax[sel]] = 0.0
+    sel = kind == 5                                    # axis-parallel
+    keep = rng.integers(0, 3, n)
+    for a in range(3):
+        d[sel & (keep != a), a] = 0.0
+    sel = kind == 6                                    # along an edge, starting on it
+    tri = rng.integers(0, len(verts) // 3, sel.sum()) * 3
+    o[sel] = verts[tri]
+    d[sel] = verts[tri + 1] - verts[tri]
+    sel = kind == 7                                    # denormal / tiny components
+    d[sel, ax[sel]] = np.float32(rng.choice([1e-42, -1e-42, 1e-38, 1e-30]))
+    sel = kind == 8                                    # huge components
+    d[sel] *= np.float32(1e30)
+    sel = kind == 9                                    # negative zero components
+    d[sel, ax[sel]] = np.float32(-0.0)
+    rays["origin"], rays["direction"] = o, d
+    t = np.full(n, 3.402823466e+38, np.float32)
+    lim = rng.integers(0, 10, n)
+    t[lim == 0] = rng.uniform(0.0, 3.0, (lim == 0).sum()).astype(np.float32)
+    t[lim == 1] = 0.0
+    t[lim == 2] = np.float32(-1.0)
+    t[(kind == 10) & (lim == 3)] = np.inf
+    rays["t"] = t
+    sel = kind == 11                                   # non-finite inputs
+    bad = rng.integers(0, 4, n)
+    rays["direction"][sel & (bad == 0), 0] = np.nan
+    rays["origin"][sel & (bad == 1), 1] = np.inf
+    rays["direction"][sel & (bad == 2), 2] = -np.inf
+    rays["direction"][sel & (bad == 3)] = 0.0
+    return rays
+
+
+def test_adversarial_rays_intersect_and_trace(rt, oracle, abi):
+    """≙ BvhInterface::intersect and getFinalColor on rays built to sit on the special cases."""
+    from conftest import bits
+    globals()["abi"] = abi
+    n_cases = int(os.environ.get("FUZZ_RAY_CASES", "30"))
+    seed0 = int(os.environ.get("FUZZ_SEED", "1"))
+    bad = []
+    n_hits = n_rays = n_lit = 0
+    t_start = time.time()
+    for case in range(n_cases):
+        seed = 77000 + seed0 + case
+        rng = np.random.default_rng(seed)
+        scene = make_scene(rng)
+        flags, params = make_flags(rng, scene)
+        for k in ("enableMultipleRaysPerPixel", "enableDepthOfField", "enableBloomEffect"):  # pixel-loop features
+            flags[k] = 0
+        f, p = abi.Features.make(**flags), abi.RenderParams.make(**params)
+        bvh, ob = rt.bvh(rt.scene(scene), f), oracle.build(scene, f)
+        rays = adversarial_rays(abi, rng, scene, 3000 if flags["enableAccelStructure"] else 600)
+        msg = []
+        got_rays, got = rt.intersect_batch(bvh, rays, f)
+        want_rays, want, _ = oracle.intersect_batch(ob, rays, f)
+        if not np.array_equal(got["hit"], want["hit"]):
+            msg.append(f"hit flags differ at {(got['hit'] != want['hit']).sum()}")
+        elif not np.array_equal(got["prim"], want["prim"]):
+            msg.append(f"prim ids differ at {(got['prim'] != want['prim']).sum()}")
+        elif not np.array_equal(bits(got_rays["t"]), bits(want_rays["t"])):
+            msg.append(f"t differs at {(bits(got_rays['t']) != bits(want_rays['t'])).sum()}")
+        else:
+            hit = want["hit"] == 1
+            if not np.array_equal(bits(got["normal"][hit]), bits(want["normal"][hit])):
+                msg.append("normals differ")
+        n_hits, n_rays = n_hits + int(want["hit"].sum()), n_rays + len(rays)
+        rgb = rt.trace_batch(bvh, rays, f, p)
+        orgb, _ = oracle.trace_batch(ob, rays, f, p)
+        n_lit += int((np.nan_to_num(orgb) != 0).any(axis=1).sum())
+        ng, nw = np.isnan(rgb), np.isnan(orgb)
+        if not np.array_equal(ng, nw):
+            msg.append(f"trace: NaN positions differ {ng.sum()} vs {nw.sum()}")
+        else:
+            ok = ~nw & np.isfinite(orgb)
+            err = np.abs(rgb[ok].astype(np.float64) - orgb[ok].astype(np.float64))
+            lim = RTOL * np.abs(orgb[ok].astype(np.float64)) + ATOL
+            if (err > lim).any():
+                msg.append(f"trace: {(err > lim).sum()} colour values off, max error {err.max():.3e}")
+            inf_ok = np.array_equal(rgb[~nw & ~np.isfinite(orgb)], orgb[~nw & ~np.isfinite(orgb)])
+            if not inf_ok:
+                msg.append("trace: infinite colour values differ")
+        if msg:
+            on = [k for k, v in flags.items() if v]
+            bad.append(f"seed {seed} tris {scene.n_triangles} spheres {len(scene.spheres)} {on} {params}: " + "; ".join(msg))
+            print("MISMATCH", bad[-1], flush=True)
+        if case % 25 == 24:
+            print(f"... {case + 1} cases, {len(bad)} bad, {time.time() - t_start:.0f} s", flush=True)
+    print(f"adversarial rays: {n_rays} rays, {n_hits} hits, {n_lit} non-black colours", flush=True)
+    assert n_hits > n_rays // 20 and n_lit > n_rays // 50, "the rays must hit and light something"
+    assert not bad, f"{len(bad)} of {n_cases} adversarial-ray cases differ:\n" + "\n".join(bad[:10])
