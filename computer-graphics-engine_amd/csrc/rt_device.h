@@ -173,8 +173,9 @@ RT_DEV uint32_t entry_ray(uint32_t e) { return e & 63u; }
 // for everything else.
 struct RayInv {
     float y[3]; // RN(1 / d[a])
-    uint32_t guard; // bit a: axis a may use the reciprocal; bit 3: all three may AND the origin is
-                    // finite (then no component of d is zero, and no slab quotient can be NaN)
+    uint32_t guard; // bit a: axis a may use the reciprocal; bit 3: all three may AND |origin| + the scene's
+                    // largest |coordinate| < 2^60 (then no component of d is zero, no slab quotient can be
+                    // NaN, and every numerator bound - origin of a finite box is below 2^61)
     RT_DEV bool ok(int a) const { return (guard >> a) & 1u; }
     RT_DEV bool all_ok() const { return (guard & 8u) != 0u; }
     float slack; // rho * max_a |1/d[a]|: how far a slab plane moved by rho shifts t (pruning bound)
@@ -200,8 +201,8 @@ RT_DEV RayInv make_ray_inv(const RayL& r, float extent)
     const float S = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fmaxf(fabsf(r.o.z), extent));
     v.slack = (S * 1.52587890625e-05f) * ymax;
     const float omax = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
-    const bool o_finite = r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z && omax < __builtin_inff();
-    if (v.guard == 7u && o_finite)
+    const bool o_small = r.o.x == r.o.x && r.o.y == r.o.y && r.o.z == r.o.z && omax + extent < 0x1p60f;
+    if (v.guard == 7u && o_small)
         v.guard = 15u;
     return v;
 }
@@ -296,13 +297,13 @@ RT_DEV void box_pair_hit(const float llo[3], const float lhi[3], const float rlo
         n[6 + a] = rlo[a] - o[a];
         n[9 + a] = rhi[a] - o[a];
     }
-    float amin = fabsf(n[0]), amax = fabsf(n[0]);
+    // the numerators' upper bound is the ray's (RayInv::all_ok: finite boxes lie within the scene's extent);
+    // the lower one is per box
+    float amin = fabsf(n[0]);
 #pragma unroll
-    for (int i = 1; i < 12; i++) {
-        amin = fminf(amin, fabsf(n[i])); // fminf / fmaxf skip a NaN numerator: it needs no guard,
-        amax = fmaxf(amax, fabsf(n[i])); // both paths turn it into a NaN quotient
-    }
-    if (inv.all_ok() && bounds_finite && amin >= 0x1p-60f && amax < 0x1p61f) {
+    for (int i = 1; i < 12; i++)
+        amin = fminf(amin, fabsf(n[i]));
+    if (inv.all_ok() && bounds_finite && amin >= 0x1p-60f) {
         // Every quotient is finite here, so IEEE min / max (v_min_f32, v_max3_f32: one
         // instruction each) agree with the reference's compare-and-select up to the sign
         // of a zero, which no comparison below can see; slab_decide() reduces to
