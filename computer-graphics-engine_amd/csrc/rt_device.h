@@ -324,8 +324,10 @@ RT_DEV void box_pair_hit(const float llo[3], const float lhi[3], const float rlo
         const float tout_r = fminf(fminf(fmaxf(q[6], q[9]), fmaxf(q[7], q[10])), fmaxf(q[8], q[11]));
         lb_l = tin_l * 0.99999904632568359375f - inv.slack;
         lb_r = tin_r * 0.99999904632568359375f - inv.slack;
-        hl = tin_l < 0.0f ? tout_l > 0.0f : tin_l <= tout_l;
-        hr = tin_r < 0.0f ? tout_r > 0.0f : tin_r <= tout_r;
+        // = tin < 0 ? tout > 0 : tin <= tout (no NaN here), written as lane-mask logic: three compares and
+        // scalar and / or instead of value selects
+        hl = (tin_l <= tout_l) & ((tout_l > 0.0f) | (tin_l >= 0.0f));
+        hr = (tin_r <= tout_r) & ((tout_r > 0.0f) | (tin_r >= 0.0f));
     } else {
         float tl_l[3], th_l[3], tl_r[3], th_r[3];
         slab_quotients(llo, lhi, r, inv, tl_l, th_l);
