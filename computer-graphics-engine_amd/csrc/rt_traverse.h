@@ -128,7 +128,8 @@ RT_DEV void leaf_phase(WaveLds& L, BufRsrc leafg, BufRsrc groups, uint32_t first
             const uint32_t pi = (e >> 3) & 0xffu, g = e & 7u;
             const uint32_t refw = L.lq_ref[pi], cw = L.lq_cw[pi];
             const uint32_t r = refw >> 26;
-            if (rank != 31u && !(any_hit_slot<MODE>(r) && L.best[r] != kNoHit)) {
+            const bool done = any_hit_slot<MODE>(r) & (L.best[r] != kNoHit); // read for every slot: no divergent branch
+            if (rank != 31u && !done) {
                 float4 c[3];
                 load_leaf(leafg, ((cw >> 6) + g) * 4u + j, c);
 #if defined(RT_DIAG) && RT_DIAG == 2 // the same three loads from a second copy of the leaf array
@@ -155,15 +156,18 @@ RT_DEV void leaf_phase(WaveLds& L, BufRsrc leafg, BufRsrc groups, uint32_t first
             const uint32_t refw = L.lq_ref[first + p], cw = L.lq_cw[first + p];
             const float lb = L.lq_lb[first + p];
             const uint32_t r = refw >> 26;
+            // one read of the ray's state, the same for closest-hit and any-hit slots (no divergent branch)
             const bool any = any_hit_slot<MODE>(r);
-            const float lim = any ? L.rayB[r].z : ray_limit(L, r);
-            const bool skip = any ? (L.best[r] != kNoHit) : (prune && lb > lim);
+            const float4 rb = L.rayB[r];
+            const unsigned long long bk = L.best[r];
+            const uint32_t t0b = __float_as_uint(rb.z), bb = (uint32_t)(bk >> 32);
+            const float lim = __uint_as_float((any || t0b < bb) ? t0b : bb); // ray_limit(), t0 for shadow rays
+            const bool skip = (any & (bk != kNoHit)) | (!any & prune & (lb > lim));
             if (g * 4u < (cw & 63u) && !skip) {
                 const uint32_t off = ((cw >> 6) + g) * 32u;
                 const float4 g0 = buf_load16(groups, off), g1 = buf_load16(groups, off + 16u);
                 alive = true;
                 if (prune) {
-                    const float4 rb = L.rayB[r];
                     if (__float_as_uint(rb.w) & 8u) // reciprocals usable on all three axes, finite origin
                         alive = group_may_hit(g0, g1, L.rayA[r], rb, L.rayC[r], lim);
                     if (COUNT)
@@ -201,25 +205,24 @@ struct Walk {
     uint32_t lane;
     bool prune;
     uint32_t lq_n; // leaf-queue fill (wave-uniform)
-    // ray cached in registers (slot cur_r of the LDS ray table)
+    // the current entry's ray (load_ray)
     RayL cur;
     RayInv cur_inv;
-    uint32_t cur_r;
 #ifdef RT_STAMPS
     unsigned long long st_node = 0, st_leaf = 0, st_steal = 0, n_node = 0, n_leaf = 0;
     unsigned long long st_pop = 0, st_load = 0, st_alu = 0, st_push = 0; // finer split of the node step
 #endif
 
-    RT_DEV void load_ray(uint32_t r)
+    // Ray slot r of the LDS ray table into registers; returns the bits of its initial limit t0. Read on every
+    // node step: skipping the reads when the lane stays on one ray costs more (a divergent branch) than they do.
+    RT_DEV uint32_t load_ray(uint32_t r)
     {
-        if (r != cur_r) {
-            const float4 a = L.rayA[r], b = L.rayB[r], c = L.rayC[r];
-            cur.o = mk(a.x, a.y, a.z);
-            cur.d = mk(a.w, b.x, b.y);
-            cur_inv.y[0] = c.x, cur_inv.y[1] = c.y, cur_inv.y[2] = c.z, cur_inv.slack = c.w;
-            cur_inv.guard = __float_as_uint(b.w);
-            cur_r = r;
-        }
+        const float4 a = L.rayA[r], b = L.rayB[r], c = L.rayC[r];
+        cur.o = mk(a.x, a.y, a.z);
+        cur.d = mk(a.w, b.x, b.y);
+        cur_inv.y[0] = c.x, cur_inv.y[1] = c.y, cur_inv.y[2] = c.z, cur_inv.slack = c.w;
+        cur_inv.guard = __float_as_uint(b.w);
+        return __float_as_uint(b.z);
     }
 
     // append the lanes' (ray r, leaf ref / count word, lb) pairs for which `want` is set;
@@ -275,7 +278,8 @@ struct Walk {
 
     // Box tests of one node pair for ray slot r (already cached): returns which
     // children to descend into, with their lower bounds.
-    RT_DEV void test_pair(const float llo[3], const float lhi[3], const float rlo[3], const float rhi[3], uint32_t r,
+    // `lim`: the ray's pruning limit (shadow rays: the initial limit t0 = 1; else min(t0, best t so far))
+    RT_DEV void test_pair(const float llo[3], const float lhi[3], const float rlo[3], const float rhi[3], float lim,
         bool& hl, bool& hr, float& lb_l, float& lb_r)
     {
         box_pair_hit(llo, lhi, rlo, rhi, cur, cur_inv, sv.bounds_finite != 0u, hl, hr, lb_l, lb_r);
@@ -283,10 +287,9 @@ struct Walk {
             lc.box += 2;
             lc.node_fetch++;
         }
-        if (prune) { // shadow rays: against the initial limit (t0 = 1)
-            const float lim = any_hit_slot<MODE>(r) ? L.rayB[r].z : ray_limit(L, r);
-            hl = hl && !(lb_l > lim);
-            hr = hr && !(lb_r > lim);
+        if (prune) {
+            hl = hl & !(lb_l > lim);
+            hr = hr & !(lb_r > lim);
         }
     }
 
@@ -356,9 +359,13 @@ struct Walk {
                 have = false;
                 const float e_lb = entry_lb(e);
                 r = entry_ray(e);
-                const bool skip = any_hit_slot<MODE>(r) ? (L.best[r] != kNoHit) : (prune && e_lb > ray_limit(L, r));
+                // one read of the ray's state serves the skip test and the pruning of the children
+                const bool any = any_hit_slot<MODE>(r);
+                const unsigned long long bk = L.best[r];
+                const uint32_t t0b = load_ray(r), bb = (uint32_t)(bk >> 32);
+                const float lim = __uint_as_float((any || t0b < bb) ? t0b : bb); // ray_limit(), t0 for shadow rays
+                const bool skip = (any & (bk != kNoHit)) | (!any & prune & (e_lb > lim));
                 if (!skip) {
-                    load_ray(r);
                     const uint32_t noff = entry_node(e) * 64u;
                     const float4 q0 = buf_load16(nodes, noff);       // l_lo xyz, l_hi x
                     const float4 q1 = buf_load16(nodes, noff + 16u); // l_hi yz, r_lo xy
@@ -376,7 +383,7 @@ struct Walk {
                     const float llo[3] = { q0.x, q0.y, q0.z }, lhi[3] = { q0.w, q1.x, q1.y };
                     const float rlo[3] = { q1.z, q1.w, q2.x }, rhi[3] = { q2.y, q2.z, q2.w };
                     bool hl, hr;
-                    test_pair(llo, lhi, rlo, rhi, r, hl, hr, lb_l, lb_r);
+                    test_pair(llo, lhi, rlo, rhi, lim, hl, hr, lb_l, lb_r);
 #if defined(RT_DIAG) && RT_DIAG == 3 // the slab arithmetic once more (children swapped), result unused
                     {
                         bool xl, xr;
@@ -447,7 +454,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     L.best[lane] = kNoHit;
     Walk<MODE, COUNT> w { sv, L, make_rsrc(use_bvh ? sv.leaf : sv.leaf_flat, sv.n_prims * 48u),
         make_rsrc(sv.nodes, sv.n_pairs * 64u), make_rsrc(sv.leaf_grouped, sv.n_groups * 4u * 48u),
-        make_rsrc(sv.groups, sv.n_groups * 32u), !NO_SPHERES && sv.prune_ok == 0u, lc, lane, prune, 0u, ray, inv, lane };
+        make_rsrc(sv.groups, sv.n_groups * 32u), !NO_SPHERES && sv.prune_ok == 0u, lc, lane, prune, 0u, ray, inv };
 #ifdef RT_STAMPS
     const unsigned long long stamp_begin = clock64();
 #endif

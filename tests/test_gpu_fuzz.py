@@ -98,6 +98,8 @@ def make_flags(rng, scene):
              rays_per_reflection=int(rng.integers(1, 3)), bloom_threshold=float(rng.uniform(0.05, 0.6)))
     if not f["enableAccelStructure"] and scene.n_triangles > 2000:
         p["depth"] = min(p["depth"], 2)   # brute force x path trees: minutes of oracle time per case otherwise
+    if f["enableRecursive"] and f["enableTransparency"]:
+        p["depth"] = min(p["depth"], 3)   # up to three calls per hit (render.cpp:97-122): 3^depth paths per ray
     return f, p
 
 
