@@ -371,18 +371,12 @@ RT_DEV bool tri_candidate_leaf(V3 v0, V3 v1, V3 v2, V3 n, const RayL& r, float t
 {
     const float D = dot(v0, n);
     tt = (D - dot(r.o, n)) / dot(r.d, n);
-    if (!(tt >= 0.0f))
-        return false;
-    if (!(t0 >= tt))
-        return false;
+    // The reference's early returns (A.1, A.2) as one conjunction: with up to 64 triangles in flight some lane
+    // nearly always reaches the last edge test, so branches only cost; every comparison is false for NaN as there.
     const V3 p = r.d * tt + r.o;
-    if (!(dot(cross(v2 - v0, n), p - v0) >= 0.0f))
-        return false;
-    if (!(dot(cross(v0 - v1, n), p - v1) >= 0.0f))
-        return false;
-    if (!(dot(cross(v1 - v2, n), p - v2) >= 0.0f))
-        return false;
-    return true;
+    const float e0 = dot(cross(v2 - v0, n), p - v0), e1 = dot(cross(v0 - v1, n), p - v1);
+    const float e2 = dot(cross(v1 - v2, n), p - v2);
+    return (tt >= 0.0f) & (t0 >= tt) & (e0 >= 0.0f) & (e1 >= 0.0f) & (e2 >= 0.0f);
 }
 
 // A.3 intersectRayWithShape(Sphere): assumes |direction| = 1, strict t < ray.t
