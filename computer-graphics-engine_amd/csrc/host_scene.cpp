@@ -220,8 +220,8 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
     const uint32_t n = scene.n_prims();
     if (n == 0)
         return "empty scene (the reference throws bad_optional_access, bvh.cpp:132)";
-    if (n >= (1u << 26))
-        return "more than 2^26 primitives: a leaf count no longer fits the leaf-queue entry (rt_device.h)";
+    if (n >= (1u << 25))
+        return "more than 2^25 primitives: a leaf count no longer fits the count word (rt_layout.h)";
     Builder b;
     b.out = this;
     b.sah = sah_binning;
@@ -406,7 +406,7 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
         if (c.leaf) {
             ref = leaf_dev_beg[node];
             const uint32_t n_leaf = (uint32_t)(c.end - c.beg);
-            cnt = leaf_group_beg[node] != 0xffffffffu ? (n_leaf | (leaf_group_beg[node] << 6)) : (0x80000000u | n_leaf);
+            cnt = leaf_group_beg[node] != 0xffffffffu ? (n_leaf | (leaf_group_beg[node] << 6)) : cw_make_big(n_leaf);
         } else
             ref = (uint32_t)pair_of[node], cnt = 0;
     };
@@ -422,7 +422,7 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
     }
     child_ref(root, root_ref, root_cnt);
     if (root_cnt != 0u) // a root that is a leaf takes the ungrouped path (one range per ray)
-        root_cnt = 0x80000000u | (uint32_t)(nodes[root].end - nodes[root].beg);
+        root_cnt = cw_make_big((uint32_t)(nodes[root].end - nodes[root].beg));
     bounds_finite = true;
     for (const NodePair& p : pairs)
         for (int a = 0; a < 3; a++)

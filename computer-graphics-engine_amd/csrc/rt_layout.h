@@ -89,12 +89,14 @@ constexpr uint32_t kGroupLeafMax = 32; // leaves with more primitives (or sphere
 
 // Child count word of a NodePair / the root reference:
 //   0                      internal node (ref = NodePair index)
-//   bit 31 set             ungrouped leaf: count = word & 0x7fffffff, primitives leaf[ref .. ref + count)
+//   bit 31 set             ungrouped leaf: count = (word & 0x7fffffff) >> 6 (bits 5:0 are zero, so the grouped
+//                          leaves' `word & 63` sees no group in it), primitives leaf[ref .. ref + count)
 //   otherwise              grouped leaf: count = word & 63 (1..32), first group = word >> 6;
 //                          group g covers slots (first + g) * 4 + [0, 4) of leaf_grouped
 RT_LAYOUT_FN bool cw_is_leaf(uint32_t w) { return w != 0u; }
 RT_LAYOUT_FN bool cw_is_big(uint32_t w) { return (w >> 31) != 0u; }
-RT_LAYOUT_FN uint32_t cw_big_count(uint32_t w) { return w & 0x7fffffffu; }
+RT_LAYOUT_FN uint32_t cw_big_count(uint32_t w) { return (w & 0x7fffffffu) >> 6; }
+RT_LAYOUT_FN uint32_t cw_make_big(uint32_t count) { return 0x80000000u | (count << 6); }
 
 // Material slot (framework mesh.h:22-34 without the shared_ptr)
 struct alignas(16) MaterialRec {

@@ -225,24 +225,10 @@ struct Walk {
         return __float_as_uint(b.z);
     }
 
-    // append the lanes' (ray r, leaf ref / count word, lb) pairs for which `want` is set;
-    // ungrouped leaves (rt_layout.h count word) are tested at once, the whole wave on each
+    // append the lanes' (ray r, leaf ref / count word, lb) pairs for which `want` is set (grouped and
+    // ungrouped leaves alike: flush_leaves tells them apart)
     RT_DEV void queue_leaves(bool want, uint32_t r, uint32_t ref, uint32_t cw, float lb)
     {
-        uint64_t big = ballot(want && cw_is_big(cw));
-        if (big) {
-            wave_lds_fence();
-            while (big) {
-                const uint32_t src = (uint32_t)__builtin_ctzll(big);
-                big &= big - 1;
-                const uint32_t rr = read_lane(r, src), bref = read_lane(ref, src), bcnt = cw_big_count(read_lane(cw, src));
-                const float blb = __uint_as_float(read_lane(__float_as_uint(lb), src));
-                if (any_hit_slot<MODE>(rr) ? (L.best[rr] != kNoHit) : (prune && blb > ray_limit(L, rr)))
-                    continue;
-                flat_range<MODE, COUNT>(L, leaf, spheres, rr, bref, bcnt, lane, lc);
-            }
-            want = want && !cw_is_big(cw);
-        }
         const uint64_t m = ballot(want);
         if (m) {
             if (want) {
@@ -255,6 +241,25 @@ struct Walk {
         }
     }
 
+    // Ungrouped leaves among the queue's entries (rt_layout.h count word: leaves above kGroupLeafMax
+    // primitives, scenes with spheres, a root that is a leaf, the brute-force mode): the whole wave on each,
+    // one primitive per lane. Kept out of the node loop — most scenes have none.
+    RT_DEV void flush_ungrouped()
+    {
+        for (uint32_t base = 0; base < lq_n; base += 64u) {
+            const uint32_t i = base + lane;
+            uint64_t big = ballot(i < lq_n && cw_is_big(L.lq_cw[i]));
+            while (big) {
+                const uint32_t k = base + (uint32_t)__builtin_ctzll(big);
+                big &= big - 1;
+                const uint32_t refw = L.lq_ref[k], rr = refw >> 26;
+                if (any_hit_slot<MODE>(rr) ? (L.best[rr] != kNoHit) : (prune && L.lq_lb[k] > ray_limit(L, rr)))
+                    continue;
+                flat_range<MODE, COUNT>(L, leaf, spheres, rr, refw & 0x3ffffffu, cw_big_count(L.lq_cw[k]), lane, lc);
+            }
+        }
+    }
+
     // Flush early: a leaf step keeps all 64 lanes busy with any two entries, and the
     // sooner a leaf is tested the sooner its hit prunes the rest of the tree.
     RT_DEV void flush_leaves(uint32_t threshold)
@@ -264,6 +269,7 @@ struct Walk {
             const unsigned long long ts = clock64();
 #endif
             wave_lds_fence();
+            flush_ungrouped(); // the grouped phases below see no group in those entries (count word bits 5:0 = 0)
             while (lq_n > 0u) {
                 const uint32_t n = lq_n < 64u ? lq_n : 64u;
                 lq_n -= n;
@@ -460,7 +466,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
 #endif
 
     if (!use_bvh || sv.root_cnt != 0u) // the root is a leaf / brute force: one ungrouped range per ray
-        w.queue_leaves(active, lane, use_bvh ? sv.root_ref : 0u, use_bvh ? sv.root_cnt : (0x80000000u | sv.n_prims), 0.0f);
+        w.queue_leaves(active, lane, use_bvh ? sv.root_ref : 0u, use_bvh ? sv.root_cnt : cw_make_big(sv.n_prims), 0.0f);
     else // the root's own box is never tested (bvh.cpp:313)
         w.lane_engine(0u, active, sv.root_ref, 0.0f);
     w.flush_leaves(1u);

@@ -37,11 +37,15 @@ for flight in [int(x) for x in os.environ.get("FLIGHTS", "1,2,8,16").split(",")]
     R = sharding.StripRenderer(rt, bvh, cam, f, p, cfg.width, cfg.height, 0, 1, frames_in_flight=flight, exchange_always=True, exchange_batch=batch)
     if emulate > 1:
         R.rows = sharding.strip_rows_of_rank(cfg.height, 8, 0, emulate)
+    dup = int(os.environ.get("ROWDUP", "1"))   # the share's rows `dup` times in one launch: what a launch of dup frames would cost
+    if dup > 1:
+        import numpy as np
+        R.rows = np.tile(R.rows, dup)
     for _ in range(40): R.step(st)
     R.finish()
     n = 320
     t0 = time.perf_counter()
     for _ in range(n): R.step(st)
     t1 = time.perf_counter(); R.finish(); t2 = time.perf_counter()
-    print(f"skip [{skip}] batch {batch} emulate {emulate} tile {tw},{th} flight {flight}: host enqueue {1e6*(t1-t0)/n:.1f} us/frame, total {1e3*(t2-t0)/n:.4f} ms/frame", flush=True)
+    print(f"skip [{skip}] batch {batch} emulate {emulate} tile {tw},{th} flight {flight}: host enqueue {1e6*(t1-t0)/n:.1f} us/frame, total {1e3*(t2-t0)/n:.4f} ms/launch = {1e3*(t2-t0)/n/dup:.4f} ms/frame at {dup} frames per launch", flush=True)
 dist.destroy_process_group()
