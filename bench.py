@@ -63,8 +63,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="successive frames on alternating HIP streams, so that the tail of frame k (a few long "
-                         "path trees) overlaps the start of the next frames; default 2 on one GPU and 8 on several "
-                         "(a rank's share of a frame is small, so more of them fit the chip at once); "
+                         "path trees) overlaps the start of the next launch (default 2); "
                          "1 = strictly one frame at a time")
     ap.add_argument("--tile-log", type=int, nargs=2, default=None, metavar=("W", "H"),
                     help="primary tile = 2^W x 2^H pixels per wave (default: 2 3 with frames in flight, else the "
@@ -72,6 +71,10 @@ def main():
     ap.add_argument("--exchange-batch", type=int, default=None,
                     help="several GPUs: successive frames that share one all-gather + one de-interleave launch "
                          "(default 8); every frame is still rendered and assembled")
+    ap.add_argument("--frames-per-launch", type=int, default=None,
+                    help="successive frames rendered by ONE launch (rt_render_device_frames; default 8): a launch of "
+                         "several frames has no idle tail between them — what a rank's small share of a frame needs "
+                         "at 8 ranks, and worth 5 %% on one GPU; every frame is rendered in full")
     ap.add_argument("--exchange-always", action="store_true",
                     help="one GPU: take the strips + RCCL exchange path with a one-rank group (what the N > 1 run "
                          "adds on top of the render: packed strips, all-gather, de-interleave), for measurement")
@@ -82,7 +85,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.frames_in_flight is None:
-        args.frames_in_flight = 2 if world == 1 else 8
+        args.frames_in_flight = 2
+    if args.frames_per_launch is None:
+        args.frames_per_launch = 8
     if args.exchange_batch is None:
         args.exchange_batch = 1 if world == 1 else 8
     # HIP runtime setting, read when the runtime starts: how many hardware queues the streams of this
@@ -154,8 +159,18 @@ def main():
     rays_per_frame = total["rays"]
 
     # ---- warmup ----------------------------------------------------------------
-    for _ in range(args.warmup):
-        renderer.step(stream)
+    fpl = max(1, args.frames_per_launch)
+    if renderer.sharded and renderer.batch % fpl:
+        fpl = 1
+
+    def run_frames(n):
+        """n frames: launches of fpl frames, the rest one by one (every frame rendered in full)"""
+        for _ in range(n // fpl):
+            renderer.step(stream, frames=fpl)
+        for _ in range(n % fpl):
+            renderer.step(stream)
+
+    run_frames(args.warmup)
     renderer.finish()     # nothing of the warmup (a partial exchange batch) is left for the timed region
 
     # ---- timed steps -----------------------------------------------------------
@@ -169,8 +184,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        renderer.step(stream)
+    run_frames(args.steps)
     renderer.finish()
     torch.cuda.synchronize()
     if world > 1:
@@ -238,6 +252,7 @@ def main():
                        "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather(overlapped" + (f",{renderer.batch}-frames-each)" if renderer.batch > 1 else ")")
                                                               if renderer.sharded else "")
                        + (f"+{renderer.flight}-frames-in-flight" if renderer.flight > 1 else "")
+                       + (f"+{fpl}-frames-per-launch" if fpl > 1 else "")
                        + ("+REHEARSAL-gloo-one-device" if rehearsal else ""),
                        "device": devname, "bvh_build_s": round(build_s, 3)},
             "roofline": roofline, "cpu_baseline": cpu,

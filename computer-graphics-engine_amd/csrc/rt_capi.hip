@@ -88,6 +88,7 @@ struct Scratch {
     DevBuf<uint32_t> counts;
     DevBuf<int32_t> rows;
     std::vector<int32_t> rows_host;
+    std::vector<rt::CameraPose> poses; // rt_render_device_frames: the frames' poses of the launch being enqueued
     DevBuf<uint32_t> order; // tile dispatch order (tile_order_for)
     DevBuf<float> samples;   // per-sample colours of multi-sample frames (k_resolve input)
     DevBuf<float> frames;    // k_trace_general: per-wave-slot recursion frames
@@ -250,6 +251,7 @@ std::vector<rt::LeafRecord> leaf_records(const std::vector<rt::PrimRecord>& recs
 rt::CameraArgs camera_args(const rt_camera& c, int32_t w, int32_t h)
 {
     rt::CameraArgs a;
+    memset(&a, 0, sizeof(a));
     memcpy(a.origin, c.origin, 12);
     memcpy(a.quat, c.quat, 16);
     a.half_w = c.half_w, a.half_h = c.half_h;
@@ -358,9 +360,12 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
     const int64_t gh = cam.tiles_w ? cam.tiles_h : (cam.n_rows + th - 1) / th;
     // tiles are tw x th pixels: measure rings in pixels so that they are round on the screen
     // ring centre: the image centre, in tiles of the launched grid (may lie outside it)
-    const int64_t lrow_mid = cam.rows ? cam.n_rows / 2 : std::min<int64_t>(std::max<int64_t>(cam.height / 2 - cam.row0, 0), cam.n_rows - 1);
+    // several frames in the launch: every frame's rows get the rings of ONE frame (period = a frame's tile rows)
+    const int64_t frame_rows = cam.n_frames > 1 ? cam.frame_rows : cam.n_rows;
+    const int64_t period = cam.n_frames > 1 ? frame_rows / th : gh + (int64_t)cam.tile_y0;
+    const int64_t lrow_mid = cam.rows ? frame_rows / 2 : std::min<int64_t>(std::max<int64_t>(cam.height / 2 - cam.row0, 0), cam.n_rows - 1);
     const int64_t cx = (cam.vwidth / 2) / tw - (int64_t)cam.tile_x0, cy = lrow_mid / th - (int64_t)cam.tile_y0;
-    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy };
+    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period };
     if (key != sc.order_key || !sc.order.p) {
         const size_t n = (size_t)(gw * gh);
         std::vector<uint32_t> order;
@@ -372,7 +377,7 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
         std::vector<std::vector<uint32_t>> rings((size_t)(rmax / step + 2));
         for (int64_t ty = 0; ty < gh; ty++)
             for (int64_t tx = 0; tx < gw; tx++) {
-                const int64_t r = std::max(std::llabs(tx - cx) * tw, std::llabs(ty - cy) * th);
+                const int64_t r = std::max(std::llabs(tx - cx) * tw, std::llabs(ty % period - cy) * th);
                 rings[(size_t)((r + step - 1) / step)].push_back((uint32_t)(ty * gw + tx));
             }
         for (const auto& ring : rings)
@@ -428,9 +433,37 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.tile_cull = g_tile_cull.load() && !counters_dev ? 1u : 0u; // the counting pass traces every primary ray
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
+    bool rect = false;
+    if (source == rt::SRC_CAMERA && !counters_dev && (flags & rt::F_ACCEL) && !(flags & rt::F_NO_PRUNE)) {
+        rect = host_launch_rect(bvh, a.cam);
+        if (cam.n_frames > 1) { // the union of the frames' rectangles (their row ranges are all kept: a row list)
+            for (int32_t k = 0; k < cam.n_frames && k < rt::kMaxFramesPerLaunch; k++) {
+                a.poses[k] = sc.poses[(size_t)k];
+                rt::CameraArgs ck = cam;
+                memcpy(ck.origin, a.poses[k].origin, sizeof(ck.origin));
+                memcpy(ck.quat, a.poses[k].quat, sizeof(ck.quat));
+                const bool rk = host_launch_rect(bvh, ck);
+                if (k == 0)
+                    a.cam.tile_x0 = ck.tile_x0, a.cam.tiles_w = ck.tiles_w, a.cam.tile_y0 = ck.tile_y0, a.cam.tiles_h = ck.tiles_h;
+                rect = (k == 0 ? rk : rect && rk);
+                if (rect && k > 0) {
+                    const uint32_t x0 = std::min(a.cam.tile_x0, ck.tile_x0);
+                    const uint32_t x1 = std::max(a.cam.tile_x0 + a.cam.tiles_w, ck.tile_x0 + ck.tiles_w);
+                    a.cam.tile_x0 = x0, a.cam.tiles_w = x1 - x0;
+                }
+            }
+            if (rect) { // every tile row of every frame
+                const uint32_t th = 1u << a.cam.tile_hlog;
+                a.cam.tile_y0 = 0, a.cam.tiles_h = ((uint32_t)a.cam.n_rows + th - 1u) / th;
+            }
+        }
+    } else if (cam.n_frames > 1) {
+        for (int32_t k = 0; k < cam.n_frames && k < rt::kMaxFramesPerLaunch; k++)
+            a.poses[k] = sc.poses[(size_t)k];
+    }
     if (source == rt::SRC_CAMERA) {
         // the counting pass traces every primary ray; otherwise launch only the tiles that can see the scene
-        if (!counters_dev && (flags & rt::F_ACCEL) && !(flags & rt::F_NO_PRUNE) && host_launch_rect(bvh, a.cam)) {
+        if (rect) {
             // k_fold treats the items of tiles outside the launched grid as untraced (vec3(0))
             fold.vwidth = (uint32_t)a.cam.vwidth, fold.tile_wlog = a.cam.tile_wlog, fold.tile_hlog = a.cam.tile_hlog;
             fold.tile_x0 = a.cam.tile_x0, fold.tile_y0 = a.cam.tile_y0;
@@ -917,6 +950,76 @@ int rt_render_device(const rt_bvh* cbvh, const rt_camera* camera, const rt_featu
     fold.width = width, fold.height = height, fold.row0 = cam.row0, fold.packed = packed, fold.rows = cam.rows;
     fold.out = rgb_dev;
     return enqueue_frame(bvh, sc, *features, *params, cam, fold, rows == nullptr && !packed, counters_dev, stream);
+}
+
+int rt_render_device_frames(const rt_bvh* cbvh, const rt_camera* cameras, int32_t n_frames,
+    const rt_features* features, const rt_render_params* params, int32_t width, int32_t height, const int32_t* rows,
+    int32_t n_rows, int32_t packed, float* rgb_dev, uint64_t frame_stride_floats, void* hip_stream)
+{
+    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
+    if (!bvh || !cameras || !rgb_dev || !features || !params)
+        return fail(RT_ERR_INVALID, "rt_render_device_frames: null argument");
+    if (n_frames < 1 || width <= 0 || height <= 0 || (rows && n_rows < 0))
+        return fail(RT_ERR_INVALID, "rt_render_device_frames: bad frame count / resolution / row count");
+    const int32_t fr = rows ? n_rows : height; // rows of one frame
+    const size_t tight = (size_t)(packed ? fr : height) * (size_t)width * 3;
+    const size_t frame_floats = frame_stride_floats ? (size_t)frame_stride_floats : tight;
+    if (frame_floats < tight)
+        return fail(RT_ERR_INVALID, "rt_render_device_frames: frame stride smaller than a frame");
+    // One launch holds the frames when the pixel loop is the plain one (one ray per pixel, no bloom, the fused
+    // level kernel) and a frame's rows are whole tiles; anything else renders the frames one after the other.
+    const rt_features& f = *features;
+    const uint32_t th = 1u << g_tile_hlog.load();
+    bool one_launch = n_frames >= 2 && n_frames <= rt::kMaxFramesPerLaunch && height < 65536 && fr > 0 && fr % (int32_t)th == 0
+        && !f.enableMultipleRaysPerPixel && !f.enableDepthOfField && !f.enableBloomEffect && !f.enableGlossyReflection
+        && !f.enableTransparency && !(f.enableRecursive && bvh->scene->host.any_non_opaque) && g_fused.load() != 0
+        && g_fused_from.load() == 0 && g_super_log.load() == 0
+        && (uint64_t)n_frames * (uint64_t)fr * (uint64_t)width <= (1ull << 30);
+    for (int32_t k = 1; one_launch && k < n_frames; k++) // one lens for all frames (the pose is per frame)
+        one_launch = cameras[k].half_w == cameras[0].half_w && cameras[k].half_h == cameras[0].half_h;
+    if (!one_launch) {
+        for (int32_t k = 0; k < n_frames; k++) {
+            const int rc = rt_render_device(cbvh, cameras + k, features, params, width, height, rows, n_rows, packed,
+                rgb_dev + (size_t)k * frame_floats, nullptr, hip_stream);
+            if (rc != RT_OK)
+                return rc;
+        }
+        return RT_OK;
+    }
+    int rc = check_features(features, bvh);
+    if (rc == RT_OK)
+        rc = check_params(params);
+    if (rc != RT_OK)
+        return rc;
+    for (int32_t i = 0; rows && i < n_rows; i++)
+        if (rows[i] < 0 || rows[i] >= height)
+            return fail(RT_ERR_INVALID, "rt_render_device_frames: row out of range");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Scratch& sc = bvh->scratch_for(hip_stream);
+    // the launch's row list: frame k's rows, entry = row | k << 16
+    std::vector<int32_t> all((size_t)n_frames * (size_t)fr);
+    for (int32_t k = 0; k < n_frames; k++)
+        for (int32_t i = 0; i < fr; i++)
+            all[(size_t)k * fr + i] = (rows ? rows[i] : i) | (k << 16);
+    if (sc.rows_host != all) {
+        sc.rows_host.swap(all);
+        HIP_TRY(sc.rows.reserve(sc.rows_host.size()));
+        HIP_TRY(hipMemcpyAsync(sc.rows.p, sc.rows_host.data(), sc.rows_host.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+    rt::CameraArgs cam = camera_args(cameras[0], width, height);
+    cam.rows = sc.rows.p, cam.n_rows = n_frames * fr, cam.n_frames = n_frames, cam.frame_rows = fr;
+    sc.poses.resize((size_t)n_frames);
+    for (int32_t k = 0; k < n_frames; k++) {
+        const rt::CameraArgs ck = camera_args(cameras[k], width, height);
+        memcpy(sc.poses[(size_t)k].origin, ck.origin, sizeof(ck.origin));
+        memcpy(sc.poses[(size_t)k].quat, ck.quat, sizeof(ck.quat));
+    }
+    rt::FoldArgs fold;
+    memset(&fold, 0, sizeof(fold));
+    fold.width = width, fold.height = height, fold.row0 = 0, fold.packed = packed, fold.rows = cam.rows;
+    fold.n_frames = n_frames, fold.frame_items = (uint32_t)fr * (uint32_t)width, fold.frame_stride = frame_floats;
+    fold.out = rgb_dev;
+    return enqueue_frame(bvh, sc, *features, *params, cam, fold, false, nullptr, stream);
 }
 
 int rt_render(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features,

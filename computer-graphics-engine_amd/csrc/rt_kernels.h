@@ -36,6 +36,14 @@ struct CameraArgs {
     int32_t vwidth, spp, ms_n, dof_n;
     float look_at[3], focus, blur;
     uint32_t seed;
+    // Several frames in one launch (rt_render_device_frames): the row list holds frame f's rows one frame after
+    // the other, entry = row | f << 16; frame_rows entries per frame (a multiple of the tile height, so a tile
+    // never straddles two frames); frame f's origin / rotation are poses[f]. n_frames <= 1: a plain launch.
+    int32_t n_frames, frame_rows;
+};
+constexpr int32_t kMaxFramesPerLaunch = 8;
+struct CameraPose {
+    float origin[3], quat[4];
 };
 
 // One recursion level of the flattened Whitted recursion (k_trace_level).
@@ -47,6 +55,7 @@ struct LevelArgs {
     uint32_t seed;
     int32_t source;
     CameraArgs cam;
+    CameraPose poses[kMaxFramesPerLaunch]; // cam.n_frames > 1 only
     RaySoA in;
     const uint32_t* in_count; // device count for SRC_QUEUE
     uint32_t in_count_imm;    // count for SRC_RAYS
@@ -82,6 +91,9 @@ struct FoldArgs {
     // packed: same index; flipped: (H-1-y)*W + x with y = rows ? rows[local_row] : row0 + local_row
     int32_t width, height, row0, packed;
     const int32_t* rows;
+    int32_t n_frames; // > 1: rows entries are row | frame << 16, the frames follow each other in `out`
+    uint32_t frame_items;  // items (rows x width) of one frame of the launch
+    size_t frame_stride;   // floats between the frames in `out`
     float* out;
     // launched sub-grid (CameraArgs::tiles_w != 0): items of tiles outside it were never traced = vec3(0)
     uint32_t vwidth, tile_wlog, tile_hlog, tile_x0, tile_y0, tiles_w, tiles_h;

@@ -751,7 +751,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
     }
 }
 
-template <bool COUNT, bool LEAN>
+// MULTI: several frames in one launch (CameraArgs::n_frames > 1): the tile's frame comes from its row entries,
+// the camera pose from LevelArgs::poses — a variant of its own, the one-frame kernels carry none of it.
+template <bool COUNT, bool LEAN, bool MULTI = false>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const LevelArgs a)
 {
     const uint32_t lane = lane_id();
@@ -772,15 +774,30 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         active = tile_pixel(a.cam, wave, lane, x, y, lrow);
         if (active)
             item = (uint32_t)lrow * (uint32_t)a.cam.vwidth + (uint32_t)x; // x: virtual column (pixel * spp + sample)
-        if (!COUNT && a.tile_cull && a.level == 0 && a.cam.spp == 1 && a.cam.dof_n == 0 && use_bvh && prune
-            && sv.prune_ok != 0u && tile_misses_scene(a.cam, sv, active, x, y)) {
+        CameraArgs cam = a.cam;
+        if (MULTI) { // the tile's frame (wave-uniform: frame_rows is a multiple of the tile height) and its pose
+            const uint64_t m = ballot(active);
+            if (m == 0)
+                return;
+            const uint32_t f = uni((uint32_t)read_lane((uint32_t)y, (uint32_t)__builtin_ctzll(m)) >> 16);
+            y &= 0xffff;
+            const CameraPose& ps = a.poses[f < (uint32_t)kMaxFramesPerLaunch ? f : 0u];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                cam.origin[k] = ps.origin[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                cam.quat[k] = ps.quat[k];
+        }
+        if (!COUNT && a.tile_cull && a.level == 0 && cam.spp == 1 && cam.dof_n == 0 && use_bvh && prune
+            && sv.prune_ok != 0u && tile_misses_scene(cam, sv, active, x, y)) {
             if (active)
                 a.state[item] = 0u; // every primary ray of the tile misses: vec3(0) (render.cpp:149-150)
             return;
         }
         if (active) {
-            ray = camera_ray(a.cam, x, y);
-            pixel = (uint32_t)y * (uint32_t)a.cam.vwidth + (uint32_t)x;  // RNG key of the light samples
+            ray = camera_ray(cam, x, y);
+            pixel = (uint32_t)y * (uint32_t)cam.vwidth + (uint32_t)x;  // RNG key of the light samples
         }
     } else {
         const uint32_t count = a.source == SRC_QUEUE ? *a.in_count : a.in_count_imm;
@@ -970,10 +987,18 @@ __global__ __launch_bounds__(256) void k_fold(const FoldArgs a)
     if (a.width > 0 && !a.packed) {
         const int32_t lrow = (int32_t)(item / (uint32_t)a.width);
         const int32_t x = (int32_t)(item - (uint32_t)lrow * (uint32_t)a.width);
-        const int32_t y = a.rows ? a.rows[lrow] : a.row0 + lrow;
+        int32_t y = a.rows ? a.rows[lrow] : a.row0 + lrow;
+        if (a.n_frames > 1)
+            y &= 0xffff;
         o = (size_t)(a.height - 1 - y) * a.width + x; // Screen::setPixel, screen.cpp:45
     }
     float* p = a.out + 3 * o;
+    if (a.n_frames > 1) { // frame f of the launch: its items follow frame f - 1's, its pixels start at f * frame_stride
+        const uint32_t f = item / a.frame_items;
+        if (a.width > 0 && a.packed)
+            p -= 3 * (size_t)f * a.frame_items;
+        p += (size_t)f * a.frame_stride;
+    }
     p[0] = finalColor.x, p[1] = finalColor.y, p[2] = finalColor.z;
 }
 
@@ -1243,7 +1268,12 @@ void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
     const uint32_t grid = grid_for_waves(waves);
     if (count)
         hipLaunchKernelGGL((k_trace_level<true, false>), dim3(grid), dim3(kBlock), 0, s, a);
-    else if (a.lean)
+    else if (a.source == SRC_CAMERA && a.cam.n_frames > 1) {
+        if (a.lean)
+            hipLaunchKernelGGL((k_trace_level<false, true, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
+        else
+            hipLaunchKernelGGL((k_trace_level<false, false, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
+    } else if (a.lean)
         hipLaunchKernelGGL((k_trace_level<false, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
     else
         hipLaunchKernelGGL((k_trace_level<false, false>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);

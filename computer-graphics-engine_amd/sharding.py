@@ -165,12 +165,27 @@ class StripRenderer:
             self.started[j] = True
         return s
 
-    def step(self, stream: int = 0):
+    def step(self, stream: int = 0, frames: int = 1):
         """Render this rank's strips of one frame on `stream` (a raw hipStream_t, the
-        current torch stream) and exchange them."""
+        current torch stream) and exchange them. frames > 1: that many successive frames in ONE
+        launch (rt_render_device_frames; here every frame has the renderer's camera) — a launch of
+        several frames has no idle tail between them, which is what a rank's small share of a frame
+        at 8 ranks needs on top of the frames in flight. Several ranks: the frames of one call must
+        lie in one exchange batch."""
         import torch
 
         if not self.sharded:
+            if frames > 1:
+                if getattr(self, "multi", None) is None or self.multi[0].shape[0] != frames:
+                    self.multi = [torch.zeros((frames, self.H, self.W, 3), dtype=torch.float32, device="cuda")
+                                  for _ in range(self.flight)]
+                j = self.k % self.flight
+                self.k += 1
+                raw = self._render_stream(j).cuda_stream if self.flight > 1 else stream
+                self.rt.render_device_frames(self.bvh, [self.cam] * frames, self.f, self.p, self.W, self.H,
+                                             self.multi[j].data_ptr(), stream=raw)
+                self.frame = self.multi[j][frames - 1]
+                return
             if self.flight > 1:
                 j = self.k % self.flight
                 self.k += 1
@@ -195,17 +210,25 @@ class StripRenderer:
         # few long path trees) overlaps the shares of the next frames; the exchanges follow in frame
         # order on the one exchange stream (every rank issues them in the same order)
         q, b = divmod(self.k, self.batch)
+        if b + frames > self.batch:
+            raise ValueError("the frames of one launch must lie in one exchange batch")
         i = q % len(self.local)
-        j = self.k % self.flight
-        self.k += 1
+        j = (self.k // frames) % self.flight
+        self.k += frames
         cur = self._render_stream(j) if self.flight > 1 else torch.cuda.current_stream()
         raw = cur.cuda_stream if self.flight > 1 else stream
         if self.used[i]:
             cur.wait_event(self.consumed[i])  # the exchange that read this buffer last must be over
-        self.rt.render_device(self.bvh, self.cam, self.f_strips, self.p, self.W, self.H,
-                              self.local[i][b].data_ptr(), rows=self.rows, packed=True, stream=raw)
-        self.rendered[i][b].record(cur)
-        if b == self.batch - 1:
+        if frames > 1:
+            self.rt.render_device_frames(self.bvh, [self.cam] * frames, self.f_strips, self.p, self.W, self.H,
+                                         self.local[i][b].data_ptr(), rows=self.rows, packed=True,
+                                         frame_stride_floats=self.local[i][b].numel(), stream=raw)
+        else:
+            self.rt.render_device(self.bvh, self.cam, self.f_strips, self.p, self.W, self.H,
+                                  self.local[i][b].data_ptr(), rows=self.rows, packed=True, stream=raw)
+        for bb in range(b, b + frames):
+            self.rendered[i][bb].record(cur)
+        if b + frames == self.batch:
             self._exchange(i, self.batch)
 
     def _exchange(self, i, n):

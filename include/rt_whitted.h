@@ -269,6 +269,19 @@ int rt_render_device(const rt_bvh* bvh, const rt_camera* camera, const rt_featur
                      const int32_t* rows, int32_t n_rows, int32_t packed, float* rgb_dev,
                      rt_counters* counters_dev, void* hip_stream);
 
+/* -- Several frames (cameras) in ONE launch, framebuffers in HBM: frame k from cameras[k] goes to
+ *    rgb_dev + k * frame_stride_floats (0 = tight: rows_per_frame * W * 3 packed, else H * W * 3 row-flipped);
+ *    rows / n_rows / packed as in rt_render_device, the same for every frame. What the reference does
+ *    with one std::thread per camera (src/main.cpp:512-531) and what a rank of a multi-GPU job does with its
+ *    small share of successive frames: a launch of several frames has no idle tail between them. Up to 8
+ *    frames share a launch when the pixel loop is the plain one (one ray per pixel, no bloom, no glossy /
+ *    transparency recursion), the cameras share one lens and a frame's rows are whole tiles; otherwise the
+ *    frames are rendered one after the other — same results either way. ------------------------------ */
+int rt_render_device_frames(const rt_bvh* bvh, const rt_camera* cameras, int32_t n_frames,
+                            const rt_features* features, const rt_render_params* params, int32_t width,
+                            int32_t height, const int32_t* rows, int32_t n_rows, int32_t packed, float* rgb_dev,
+                            uint64_t frame_stride_floats, void* hip_stream);
+
 /* Primary-ray hit records of a frame (parity instrument: bit patterns of t and
  * prim ids at full resolution). t_bits/prim: W*H entries, row-flipped like the
  * framebuffer. Host pointers. */

@@ -41,11 +41,12 @@ for flight in [int(x) for x in os.environ.get("FLIGHTS", "1,2,8,16").split(",")]
     if dup > 1:
         import numpy as np
         R.rows = np.tile(R.rows, dup)
-    for _ in range(40): R.step(st)
+    fpl = int(os.environ.get("FPL", "1"))     # frames per launch (rt_render_device_frames)
+    for _ in range(40 // fpl): R.step(st, frames=fpl)
     R.finish()
     n = 320
     t0 = time.perf_counter()
-    for _ in range(n): R.step(st)
+    for _ in range(n // fpl): R.step(st, frames=fpl)
     t1 = time.perf_counter(); R.finish(); t2 = time.perf_counter()
-    print(f"skip [{skip}] batch {batch} emulate {emulate} tile {tw},{th} flight {flight}: host enqueue {1e6*(t1-t0)/n:.1f} us/frame, total {1e3*(t2-t0)/n:.4f} ms/launch = {1e3*(t2-t0)/n/dup:.4f} ms/frame at {dup} frames per launch", flush=True)
+    print(f"fpl {fpl} skip [{skip}] batch {batch} emulate {emulate} tile {tw},{th} flight {flight}: host enqueue {1e6*(t1-t0)/n:.1f} us/frame, total {1e3*(t2-t0)/n:.4f} ms/launch = {1e3*(t2-t0)/n/dup:.4f} ms/frame at {dup} frames per launch", flush=True)
 dist.destroy_process_group()
