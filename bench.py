@@ -66,8 +66,8 @@ def main():
                          "path trees) overlaps the start of the next launch (default 2); "
                          "1 = strictly one frame at a time")
     ap.add_argument("--tile-log", type=int, nargs=2, default=None, metavar=("W", "H"),
-                    help="primary tile = 2^W x 2^H pixels per wave (default: 2 3 with frames in flight, else the "
-                         "library's latency setting 1 3)")
+                    help="primary tile = 2^W x 2^H pixels per wave (default: 3 3 with several frames per launch and "
+                         "launches in flight, 2 3 with frames in flight only, else the library's latency setting 1 3)")
     ap.add_argument("--exchange-batch", type=int, default=None,
                     help="several GPUs: successive frames that share one all-gather + one de-interleave launch "
                          "(default 8); every frame is still rendered and assembled")
@@ -139,11 +139,15 @@ def main():
     if args.tile_log:
         rt.set_option("tile_wlog", args.tile_log[0])
         rt.set_option("tile_hlog", args.tile_log[1])
+    elif args.frames_per_launch > 1 and args.frames_in_flight > 1:
+        # Throughput setting of the library's tuning knobs: 8x8-pixel primary tiles (64 rays per wave) do the least
+        # instruction work per ray but end in the longest path-tree tails — which a launch of several frames and
+        # the next launch in flight cover (6 980 Mrays/s with 4x8 tiles, 8 030 with 8x8; a lone frame prefers
+        # the library default 2x8). Results are identical for every tile shape (tests/test_gpu_options.py).
+        rt.set_option("tile_wlog", 3)
+        rt.set_option("tile_hlog", 3)
     elif args.frames_in_flight > 1:
-        # Throughput setting of the library's tuning knobs: 4x8-pixel primary tiles (32 rays per wave; with the
-        # merged traversals all 64 ray slots are used) do 30 % less instruction work than the latency setting
-        # (2x8) but end in longer path-tree tails — which the next frame in flight covers. Results are identical.
-        rt.set_option("tile_wlog", 2)
+        rt.set_option("tile_wlog", 2)   # frames in flight only: 4x8 tiles
         rt.set_option("tile_hlog", 3)
     renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, rank, world, strip_rows=STRIP_ROWS,
                                       frames_in_flight=args.frames_in_flight, exchange_always=args.exchange_always,
