@@ -47,12 +47,13 @@ for rnd in range(ROUNDS):
         if rnd == 0:
             c = R.count_rays(stream)
             cnts[v] = c
+        FPL = int(os.environ.get('TUNE_FPL', '1'))   # frames per launch (FRAMES should be a multiple)
         for _ in range(3):
-            R.step(stream)
+            R.step(stream, frames=FPL)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(FRAMES):
-            R.step(stream)
+        for _ in range(FRAMES // FPL):
+            R.step(stream, frames=FPL)
         torch.cuda.synchronize()
         res[v].append((time.perf_counter() - t0) / FRAMES * 1e3)
 for v in values:
