@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_last_error", "rt_device_info", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
-    "rt_render_device", "rt_render_device_frames", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
+    "rt_render_device", "rt_render_device_frames", "rt_render_frames", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
     "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
     "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp", "rt_bloom_device",
 ]
@@ -135,6 +135,8 @@ class Library:
         c.rt_render_device_frames.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.c_int32, C.POINTER(abi.Features),
                                               C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                               C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p]
+        c.rt_render_frames.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.c_int32, C.POINTER(abi.Features),
+                                       C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_void_p]
         c.rt_render_hits.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Features), C.c_int32,
                                      C.c_int32, C.c_void_p, C.c_void_p]
         c.rt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(abi.Features),
@@ -265,6 +267,14 @@ class Library:
             rows_arr.ctypes.data if rows_arr is not None else None, n_rows, 1 if packed else 0,
             C.c_void_p(rgb_ptr), C.c_void_p(counters_ptr) if counters_ptr else None,
             C.c_void_p(stream) if stream else None))
+
+    # -- several cameras at once into host memory: (n, H, W, 3)
+    def render_frames(self, bvh: Bvh, cams, features, params, width, height):
+        arr = (abi.Camera * len(cams))(*cams)
+        rgb = np.zeros((len(cams), height, width, 3), np.float32)
+        self._check(self.c.rt_render_frames(bvh.handle, arr, len(cams), C.byref(features), C.byref(params), width,
+                                            height, rgb.ctypes.data))
+        return rgb
 
     # -- several frames (cameras) in one launch; frame k at rgb_ptr + k * frame bytes
     def render_device_frames(self, bvh: Bvh, cams, features, params, width, height, rgb_ptr: int, rows=None,

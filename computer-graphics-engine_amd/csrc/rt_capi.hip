@@ -1063,6 +1063,32 @@ int rt_render(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* fe
     return RT_OK;
 }
 
+int rt_render_frames(const rt_bvh* cbvh, const rt_camera* cameras, int32_t n_frames, const rt_features* features,
+    const rt_render_params* params, int32_t width, int32_t height, float* rgb)
+{
+    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
+    if (!bvh || !cameras || !rgb || !features || !params)
+        return fail(RT_ERR_INVALID, "rt_render_frames: null argument");
+    if (n_frames < 1 || width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30)
+        return fail(RT_ERR_INVALID, "rt_render_frames: bad frame count / resolution");
+    std::lock_guard<std::mutex> g(g_host_call_mu);
+    Scratch& sc = bvh->scratch_for(nullptr);
+    const size_t frame_floats = (size_t)width * height * 3;
+    // groups of up to kMaxFramesPerLaunch frames: one launch each (or one launch per frame when the frames
+    // cannot share one, rt_render_device_frames), one copy back per group
+    for (int32_t k0 = 0; k0 < n_frames; k0 += rt::kMaxFramesPerLaunch) {
+        const int32_t n = std::min<int32_t>(rt::kMaxFramesPerLaunch, n_frames - k0);
+        HIP_TRY(sc.frame.reserve(frame_floats * (size_t)n));
+        const int rc = rt_render_device_frames(cbvh, cameras + k0, n, features, params, width, height, nullptr, height, 0,
+            sc.frame.p, 0, nullptr);
+        if (rc != RT_OK)
+            return rc;
+        HIP_TRY(hipMemcpy(rgb + (size_t)k0 * frame_floats, sc.frame.p, frame_floats * (size_t)n * sizeof(float),
+            hipMemcpyDeviceToHost));
+    }
+    return RT_OK;
+}
+
 int rt_render_hits(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features, int32_t width,
     int32_t height, uint32_t* t_bits, int32_t* prim)
 {

@@ -271,17 +271,22 @@ int main(int argc, char** argv)
     std::printf("levels %d, leaves %d\n", rt_bvh_num_levels(bvh), rt_bvh_num_leaves(bvh));
 
     const float deg = 0.01745329251994329576923690768489f; // glm::radians
-    std::vector<float> frame((size_t)W * H * 3);
     const rt_render_params params { depth, 5, 25, 0, 3, 5, 3.0f, 0.005f, 0.3f, 0.4f, 0, 3, 40, 1.0f }; // the reference's defaults
     const auto r0 = clock::now();
+    // The reference renders its cameras from one std::thread each (src/main.cpp:512-531); here they go to the
+    // GPU together: rt_render_frames puts up to eight of them into one launch.
+    std::vector<rt_camera> cameras(cams.size());
     for (size_t i = 0; i < cams.size(); i++) {
-        rt_camera cam;
         const float rot[3] = { cams[i].rx * deg, cams[i].ry * deg, cams[i].rz * deg }; // glm::radians(rotation)
-        rt_camera_from_trackball(cams[i].fov * deg, float(W) / float(H), cams[i].look, cams[i].dist, rot, &cam);
-        if (rt_render(bvh, &cam, &f, &params, W, H, 0, H, frame.data(), nullptr) != RT_OK)
-            return die("rt_render", rt_last_error());
+        rt_camera_from_trackball(cams[i].fov * deg, float(W) / float(H), cams[i].look, cams[i].dist, rot, &cameras[i]);
+    }
+    const size_t frame_floats = (size_t)W * H * 3;
+    std::vector<float> frames(frame_floats * cams.size());
+    if (rt_render_frames(bvh, cameras.data(), (int32_t)cameras.size(), &f, &params, W, H, frames.data()) != RT_OK)
+        return die("rt_render_frames", rt_last_error());
+    for (size_t i = 0; i < cams.size(); i++) {
         const std::string path = out + "_cam_" + std::to_string(i) + ".bmp";
-        if (rt_write_bmp(path.c_str(), frame.data(), W, H) != RT_OK)
+        if (rt_write_bmp(path.c_str(), frames.data() + i * frame_floats, W, H) != RT_OK)
             return die("rt_write_bmp", rt_io_last_error());
         std::printf("Image %zu saved to %s\n", i, path.c_str());
     }

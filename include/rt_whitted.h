@@ -282,6 +282,11 @@ int rt_render_device_frames(const rt_bvh* bvh, const rt_camera* cameras, int32_t
                             int32_t height, const int32_t* rows, int32_t n_rows, int32_t packed, float* rgb_dev,
                             uint64_t frame_stride_floats, void* hip_stream);
 
+/* -- The same into host memory: n_frames row-flipped frames of width * height * 3 floats, one after the other
+ *    in rgb (what n calls of rt_render would write, one camera each). ----------------------------------- */
+int rt_render_frames(const rt_bvh* bvh, const rt_camera* cameras, int32_t n_frames, const rt_features* features,
+                     const rt_render_params* params, int32_t width, int32_t height, float* rgb);
+
 /* Primary-ray hit records of a frame (parity instrument: bit patterns of t and
  * prim ids at full resolution). t_bits/prim: W*H entries, row-flipped like the
  * framebuffer. Host pointers. */

@@ -68,3 +68,16 @@ def test_frames_with_ragged_rows_fall_back(rt, abi, scenes):
     torch.cuda.synchronize()
     for k, c in enumerate(cams):
         assert np.array_equal(out[k].cpu().numpy().view(np.uint32), rt.render(bvh, c, f, p, W, H).view(np.uint32))
+
+
+def test_host_pointer_frames_call(rt, abi, scenes):
+    """rt_render_frames: 11 cameras (one launch of 8, one of 3) into host memory = 11 calls of rt_render."""
+    data = scenes.load_fixture_scene("monkey")
+    f = abi.Features.make(enableShading=1, enableHardShadow=1, enableRecursive=1, enableAccelStructure=1)
+    p = abi.RenderParams.make(depth=2)
+    bvh = rt.bvh(rt.scene(data), f)
+    W, H = 96, 64
+    cams = _cams(rt, scenes, W, H, 11)
+    got = rt.render_frames(bvh, cams, f, p, W, H)
+    for k, c in enumerate(cams):
+        assert np.array_equal(got[k].view(np.uint32), rt.render(bvh, c, f, p, W, H).view(np.uint32)), f"camera {k}"
