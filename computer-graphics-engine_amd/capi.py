@@ -269,9 +269,10 @@ class Library:
             C.c_void_p(stream) if stream else None))
 
     # -- several cameras at once into host memory: (n, H, W, 3)
-    def render_frames(self, bvh: Bvh, cams, features, params, width, height):
+    def render_frames(self, bvh: Bvh, cams, features, params, width, height, out=None):
         arr = (abi.Camera * len(cams))(*cams)
-        rgb = np.zeros((len(cams), height, width, 3), np.float32)
+        rgb = out if out is not None else np.zeros((len(cams), height, width, 3), np.float32)
+        assert rgb.dtype == np.float32 and rgb.flags.c_contiguous and rgb.shape == (len(cams), height, width, 3)
         self._check(self.c.rt_render_frames(bvh.handle, arr, len(cams), C.byref(features), C.byref(params), width,
                                             height, rgb.ctypes.data))
         return rgb

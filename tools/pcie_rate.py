@@ -23,3 +23,12 @@ for _ in range(20):
 ms = 1e3 * float(np.median(ts))
 print(f"{cfg.name if hasattr(cfg,'name') else sys.argv[1:]}: rt_render to a pageable host buffer: {ms:.3f} ms per frame "
       f"({cnt.rays / ms / 1e3:.0f} Mrays/s, {W*H*12/ms/1e6:.1f} GB/s of frame bytes)")
+cams = [cam] * 8
+buf = np.zeros((8, H, W, 3), np.float32)   # the caller's buffer, reused (a fresh 200 MB array per call is page faults)
+for _ in range(2):
+    rt.render_frames(bvh, cams, f, p, W, H, out=buf)
+ts = []
+for _ in range(8):
+    t0 = time.perf_counter(); rt.render_frames(bvh, cams, f, p, W, H, out=buf); ts.append(time.perf_counter() - t0)
+ms8 = 1e3 * float(np.median(ts)) / 8
+print(f"rt_render_frames, 8 cameras per call: {ms8:.3f} ms per frame ({cnt.rays / ms8 / 1e3:.0f} Mrays/s, {W*H*12/ms8/1e6:.1f} GB/s of frame bytes)")
