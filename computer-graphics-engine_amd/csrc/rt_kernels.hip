@@ -302,10 +302,11 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
     if (flags & F_SHADING) {
         V3 result = mk(0.0f, 0.0f, 0.0f);
         const LightRec RT_CONST_AS* lights = (const LightRec RT_CONST_AS*)sv.lights;
-        // free lanes above the tile's pixels: 16-pixel tiles leave room for 4 shadow samples per
-        // traversal, 32-pixel tiles for 2
+        // Area lights: the wave's n_hit hit points take 64 / n_hit shadow samples each per traversal — lane
+        // q + j * n_hit carries the ray of the q-th hit's sample s0 + j, whatever lanes the hits sit in
         const uint64_t hit_mask = ballot(hit);
-        const uint32_t batch = (hit_mask >> 16) == 0ull ? 4u : ((hit_mask >> 32) == 0ull ? 2u : 1u);
+        const uint32_t n_hit = (uint32_t)__builtin_popcountll(hit_mask);
+        const uint32_t batch = n_hit ? 64u / n_hit : 1u;
         for (uint32_t li = 0; li < sv.n_lights; li++) {
             const LightRec RT_CONST_AS* L = lights + li;
             const int32_t kind = L->kind;
@@ -316,31 +317,36 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
             const int32_t n = a.parallelogram_n;
             const int32_t nsamp = is_point ? 1 : (kind == RT_LIGHT_SEGMENT ? a.segment_n : n * n);
             V3 acc = mk(0.0f, 0.0f, 0.0f);
-            // Area lights: B samples per traversal. The tile's pixels sit in the low lanes; lane
-            // p + j * stride carries the shadow ray of pixel p's sample s0 + j, one any-hit traversal
-            // serves all of them, and the pixel lane adds the contributions in the reference's order.
+            // One any-hit traversal serves batch samples of every hit; the pixel lane then adds the
+            // contributions in the reference's order.
             int32_t s_begin = 0;
             if (!LEAN && !GENERAL && !is_point && batch > 1u) {
                 const uint32_t lane = lane_id();
-                const uint32_t stride = 64u / batch, kk = lane / stride;
-                const int src = (int)(lane % stride);
+                const uint32_t q_mine = prefix_count(hit_mask); // this lane's rank among the hits (if it is one)
+                wave_lds_fence();
+                if (hit)
+                    wl.xfer[q_mine] = lane; // rank -> lane (xfer is free between traversals)
+                wave_lds_fence();
+                const uint32_t kk = lane / n_hit;
+                const int src = (int)wl.xfer[lane % n_hit];
+                wave_lds_fence();
                 RayL rs;
                 rs.o = mk(__shfl(ray.o.x, src, 64), __shfl(ray.o.y, src, 64), __shfl(ray.o.z, src, 64));
                 rs.d = mk(__shfl(ray.d.x, src, 64), __shfl(ray.d.y, src, 64), __shfl(ray.d.z, src, 64));
                 const float ts = __shfl(t, src, 64);
                 const uint32_t pix_s = (uint32_t)__shfl((int)pixel, src, 64);
-                const bool hit_s = __shfl((int)hit, src, 64) != 0;
                 for (int32_t s0 = 0; s0 < nsamp; s0 += (int32_t)batch) {
                     const int32_t s_mine = s0 + (int32_t)kk;
+                    const bool mine = kk < batch && s_mine < nsamp;
                     V3 lp, lcq;
-                    light_sample(L, kind, a, pix_s, level, li, s_mine < nsamp ? s_mine : 0, lp, lcq);
+                    light_sample(L, kind, a, pix_s, level, li, mine ? s_mine : 0, lp, lcq);
                     const RayL sray = shadow_ray(rs, ts, lp);
                     float st = 1.0f;
                     int32_t spos;
-                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, hit_s && s_mine < nsamp, sray, st, spos, lc, wl);
+                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, mine, sray, st, spos, lc, wl);
                     const int blocked = spos >= 0 ? 1 : 0;
                     for (uint32_t j = 0; j < batch && s0 + (int32_t)j < nsamp; j++) {
-                        const float visibility = __shfl(blocked, (int)(lane % stride + j * stride), 64) ? 0.0f : 1.0f;
+                        const float visibility = __shfl(blocked, (int)((q_mine + j * n_hit) & 63u), 64) ? 0.0f : 1.0f;
                         V3 lpos, lcol;
                         light_sample(L, kind, a, pixel, level, li, s0 + (int32_t)j, lpos, lcol);
                         V3 color = mk(0.0f, 0.0f, 0.0f);
