@@ -7,8 +7,11 @@ traversed) at 1920x1080; frame ms; 1/2/4/8-GPU scaling.
 Workload (config.workload = "C3"): the dragon-scale stand-in — 819 200-triangle
 torus knot (data/dragon.obj is absent from the reference), 1920x1080, Phong +
 hard shadows + reflections depth 4, default camera — synthetic, generated in
-process. One "step" = one full frame through rt_render_device with the scene,
-BVH and framebuffer resident in HBM.
+process. One "step" = one full frame with the scene, BVH and framebuffer resident in
+HBM. Throughput setting (defaults): a launch renders 8 successive frames
+(rt_render_device_frames), two launches are in flight on alternating HIP streams,
+8x8-pixel primary tiles; every frame is rendered in full, K steps = K frames.
+`--frames-per-launch 1 --frames-in-flight 1` is the strictly serial loop.
 
 N GPUs: one process per GPU; the frame's 8-row strips are dealt round-robin to
 the ranks, each renders its strips into a packed buffer, an RCCL all-gather
