@@ -139,19 +139,21 @@ def main():
     cam = rt.camera(*scenes.default_camera_args(W, H))
 
     stream = torch.cuda.current_stream().cuda_stream
-    if args.tile_log:
-        rt.set_option("tile_wlog", args.tile_log[0])
-        rt.set_option("tile_hlog", args.tile_log[1])
-    elif args.frames_per_launch > 1 and args.frames_in_flight > 1:
+    if args.frames_per_launch > 1:
         # Throughput setting of the library's tuning knobs: 8x8-pixel primary tiles (64 rays per wave) do the least
         # instruction work per ray but end in the longest path-tree tails — which a launch of several frames and
         # the next launch in flight cover (6 980 Mrays/s with 4x8 tiles, 8 030 with 8x8; a lone frame prefers
-        # the library default 2x8). Results are identical for every tile shape (tests/test_gpu_options.py).
+        # the library default 2x8); 64-ray waves fill a longer leaf queue before a flush pays (+1 %).
+        # Results are identical for every setting (tests/test_gpu_options.py).
         rt.set_option("tile_wlog", 3)
         rt.set_option("tile_hlog", 3)
+        rt.set_option("leaf_flush", 32)
     elif args.frames_in_flight > 1:
         rt.set_option("tile_wlog", 2)   # frames in flight only: 4x8 tiles
         rt.set_option("tile_hlog", 3)
+    if args.tile_log:
+        rt.set_option("tile_wlog", args.tile_log[0])
+        rt.set_option("tile_hlog", args.tile_log[1])
     renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, rank, world, strip_rows=STRIP_ROWS,
                                       frames_in_flight=args.frames_in_flight, exchange_always=args.exchange_always,
                                       exchange_batch=args.exchange_batch)

@@ -124,12 +124,12 @@ struct LaneCounters {
 #endif
 };
 
-// Per-wave LDS working set (9.4 KiB): ray table, best-key slots, the per-lane
+// Per-wave LDS working set (10 224 B): ray table, best-key slots, the per-lane
 // deques (slot [level][lane]: conflict-free; entry = node pair index << 6 | ray
 // slot, plus the entry's distance lower bound) and the (ray, leaf) pair queue.
 constexpr uint32_t kStackLevels = 16; // MAX_DEPTH = 16 levels ⇒ at most 15 internal levels pending
-constexpr uint32_t kLeafFlushMax = 16; // largest leaf_flush threshold (SceneView::leaf_flush)
-constexpr uint32_t kLeafQueue = 144;   // < kLeafFlushMax left over + at most 128 appended per node step
+constexpr uint32_t kLeafFlushMax = 36; // largest leaf_flush threshold (SceneView::leaf_flush)
+constexpr uint32_t kLeafQueue = 164;   // < kLeafFlushMax left over + at most 128 appended per node step
 struct alignas(16) WaveLds {
     float4 rayA[64]; // ox oy oz dx
     float4 rayB[64]; // dy dz t0 guard bits (RayInv::ok[0..2], all_ok)
@@ -142,7 +142,7 @@ struct alignas(16) WaveLds {
     uint32_t xfer[64];          // work-stealing hand-over slots
     uint32_t surv[80];          // leaf phase: surviving (pair, group) entries, < 16 left over + 64 new
 };
-static_assert(sizeof(WaveLds) == 9984, "WaveLds"); // one wave per workgroup: 16 of them fit a CU's 160 KiB
+static_assert(sizeof(WaveLds) == 10224, "WaveLds"); // one wave per workgroup: 16 x 10 240 (allocation granule) = a CU's 160 KiB
 
 // A deque entry in 32 bits: [31:21] lower bound, [20:6] node pair index, [5:0] ray slot.
 // MAX_DEPTH = 16 levels caps a tree at 32 767 internal nodes (15 bits). The bound keeps

@@ -15,7 +15,7 @@ SETTINGS = [
     dict(tile_wlog=2, tile_hlog=2), dict(tile_wlog=0, tile_hlog=0), dict(tile_wlog=3, tile_hlog=0), dict(tile_wlog=0, tile_hlog=3),
     dict(fused=0), dict(fused_from=1), dict(fused_from=2, tile_wlog=3, tile_hlog=3), dict(merge_next=0),
     dict(tile_order=0), dict(tile_cull=0), dict(launch_rect=0), dict(tile_cull=0, launch_rect=0, tile_order=0),
-    dict(super_log=1), dict(leaf_flush=1), dict(leaf_flush=4, tile_wlog=3, tile_hlog=3), dict(min_waves=1),
+    dict(super_log=1), dict(leaf_flush=1), dict(leaf_flush=32, tile_wlog=3, tile_hlog=3), dict(leaf_flush=36), dict(leaf_flush=4, tile_wlog=3, tile_hlog=3), dict(min_waves=1),
 ]
 
 

@@ -8,6 +8,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY" "GRBM_GUI_ACTIVE"; do
   N=$(echo $P | cut -d' ' -f1)
   mkdir -p $O/pmc/$N
-  timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $O/pmc/$N -- python3 bench.py --steps 8 --warmup 8 --frames-in-flight 1 --tile-log 3 3 --no-cpu-baseline --no-profile-events > $O/pmc/$N/log.txt 2>&1 || echo "pass $N failed"
+  timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $O/pmc/$N -- python3 bench.py --steps 8 --warmup 8 --frames-in-flight 1 --no-cpu-baseline --no-profile-events > $O/pmc/$N/log.txt 2>&1 || echo "pass $N failed"
 done
 echo done; tail -c 600 $O/bench_default.json
