@@ -142,7 +142,7 @@ struct alignas(16) WaveLds {
     uint32_t xfer[64];          // work-stealing hand-over slots
     uint32_t surv[80];          // leaf phase: surviving (pair, group) entries, < 16 left over + 64 new
 };
-static_assert(sizeof(WaveLds) == 10224, "WaveLds"); // one wave per workgroup: 16 x 10 240 (allocation granule) = a CU's 160 KiB
+static_assert(sizeof(WaveLds) == 10224, "WaveLds"); // one wave per workgroup: 16 of them fit a CU's 160 KiB (163 584 B)
 
 // A deque entry in 32 bits: [31:21] lower bound, [20:6] node pair index, [5:0] ray slot.
 // MAX_DEPTH = 16 levels caps a tree at 32 767 internal nodes (15 bits). The bound keeps
