@@ -28,6 +28,7 @@ JSON line (rank 0): the contract's keys plus
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -158,28 +159,64 @@ def main():
                                       frames_in_flight=args.frames_in_flight, exchange_always=args.exchange_always,
                                       exchange_batch=args.exchange_batch)
 
-    # ---- untimed counting pass: rays and tests of THIS rank's strips ------------
-    cnt = renderer.count_rays(stream)
-    keys = list(cnt.keys())
-    cvec = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(cvec)
-    total = dict(zip(keys, [int(v) for v in cvec.tolist()]))
-    rays_per_frame = total["rays"]
+    # ---- camera poses: every frame its own (the reference renders one camera per renderRayTracing call, or one
+    #      camera per thread in CLI mode, src/main.cpp:512-531): the default trackball orbits the scene once over
+    #      the timed steps (rotation.y += 360 deg * k / P, P = min(steps, 256) distinct poses)
+    fovy, aspect, look_at, dist_, rot0 = scenes.default_camera_args(W, H)
+    n_poses = max(1, min(args.steps, 256))
 
-    # ---- warmup ----------------------------------------------------------------
+    def pose(k):
+        ang = 2.0 * math.pi * (k % n_poses) / n_poses
+        return rt.camera(fovy, aspect, look_at, dist_, (rot0[0], rot0[1] + ang, rot0[2]))
+
+    cams = [pose(k) for k in range(n_poses)]
+
+    # ---- untimed counting pass: rays and tests of THIS rank's strips, per pose ----
+    keys, per_pose = None, []
+    for k in range(n_poses):
+        c = renderer.count_rays(stream, cam=cams[k])
+        keys = keys or list(c.keys())
+        per_pose.append([c[x] for x in keys])
+    per_pose = np.asarray(per_pose, dtype=np.int64)            # [pose, counter], this rank
+    per_pose_all = torch.tensor(per_pose, dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(per_pose_all)
+    per_pose_all = per_pose_all.cpu().numpy()                  # all ranks
+    reps = np.bincount(np.arange(args.steps) % n_poses, minlength=n_poses).astype(np.int64)  # timed uses of each pose
+    total = dict(zip(keys, [int(v) for v in (per_pose_all * reps[:, None]).sum(0)]))   # over the K timed frames
+    mine = dict(zip(keys, [int(v) for v in (per_pose * reps[:, None]).sum(0)]))
+    rays_total = total["rays"]
+
+    # ---- steady state before anything is timed: every buffer, every stream, every launch shape -----------------
     fpl = max(1, args.frames_per_launch)
     if renderer.sharded and renderer.batch % fpl:
         fpl = 1
 
-    def run_frames(n):
-        """n frames: launches of fpl frames, the rest one by one (every frame rendered in full)"""
-        for _ in range(n // fpl):
-            renderer.step(stream, frames=fpl)
-        for _ in range(n % fpl):
-            renderer.step(stream)
+    def launch_sizes(n):
+        """n frames as launches of fpl frames; when fpl does not divide n, as equal launches of at most fpl frames
+        whose count is a multiple of the launches in flight (20 frames, 8 per launch, 2 in flight: 4 x 5 — never
+        single frames, and every stream ends at about the same time)"""
+        if n <= 0:
+            return []
+        if n % fpl == 0:
+            return [fpl] * (n // fpl)
+        m = -(-n // fpl)
+        m = -(-m // renderer.flight) * renderer.flight
+        m = min(m, n)
+        return [n // m + (1 if i < n % m else 0) for i in range(m)]
 
-    run_frames(args.warmup)
+    sizes = launch_sizes(args.steps)
+    main_size = max(set(sizes), key=sizes.count)
+    renderer.prepare(stream, sorted(set(sizes + launch_sizes(args.warmup))))
+
+    def run_frames(first, n):
+        """frames first .. first + n - 1 of the orbit"""
+        k = first
+        for m in launch_sizes(n):
+            renderer.step(stream, frames=m, cams=[cams[q % n_poses] for q in range(k, k + m)])
+            k += m
+
+    run_frames(-args.warmup, args.warmup)
     renderer.finish()     # nothing of the warmup (a partial exchange batch) is left for the timed region
 
     # ---- timed steps -----------------------------------------------------------
@@ -189,21 +226,25 @@ def main():
     if use_events:
         for s_ in launch_streams:
             rt.profile_read(bvh, s_, reset=True)
+    renderer.start_log()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    run_frames(args.steps)
+    run_frames(0, args.steps)
     renderer.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    kernel_ms, launches = 0.0, 0
+    launch_ms = []   # (frames of the launch, trace-kernel milliseconds), every launch of the timed region
     if use_events:
-        for s_ in launch_streams:
-            ms_, n_ = rt.profile_read(bvh, s_, reset=True)
-            kernel_ms, launches = kernel_ms + ms_, launches + n_
+        for j_, s_ in enumerate(launch_streams):
+            ms_list = rt.profile_read_launches(bvh, s_, reset=True)
+            # with rt_set_option("fused", 0) a frame is depth + 1 launches: sum them per step() call
+            per = len(ms_list) // max(1, len(renderer.log[j_]))
+            for q, fr in enumerate(renderer.log[j_]):
+                launch_ms.append((fr, sum(ms_list[q * per:(q + 1) * per]), per))
     rt.profile_enable(bvh, False)
     tvec = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -211,58 +252,96 @@ def main():
     elapsed = float(tvec.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    mrays = rays_per_frame * args.steps / elapsed / 1e6
+    mrays = rays_total / elapsed / 1e6
+
+    # ---- one frame at a time (N = 1): the library's latency setting, no launches in flight ------------------
+    frame_ms_serial = None
+    if world == 1 and not args.exchange_always:
+        rt.set_option("tile_wlog", 1)
+        rt.set_option("tile_hlog", 3)
+        rt.set_option("leaf_flush", 16)
+        lone = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, 0, 1, strip_rows=STRIP_ROWS, frames_in_flight=1)
+        lone.prepare(stream, (1,))
+        n_serial = min(16, n_poses)
+        ts = []
+        for k in range(n_serial):
+            kk = k * n_poses // n_serial
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lone.step(stream, cams=[cams[kk]])
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        frame_ms_serial = {"mean": round(float(np.mean(ts)) * 1e3, 4), "min": round(min(ts) * 1e3, 4),
+                           "max": round(max(ts) * 1e3, 4), "frames": n_serial,
+                           "setting": "one frame per launch, one launch at a time, host-synchronised, 2x8-pixel tiles"}
 
     if rank == 0:
-        ab = algorithmic_bytes(total, f, W * H)
-        n_levels = (cfg.depth + 1) if f.enableRecursive else 1
+        ab = algorithmic_bytes(total, f, W * H * args.steps)
         roofline = None
-        if use_events and launches:
-            # this rank's share of the algorithmic bytes / its own kernel time
-            ab_rank = algorithmic_bytes(cnt, f, 0)["trace_kernel"]
-            # launches per frame: 1 with the default fused recursion (the wave keeps its own
-            # reflection rays), depth + 1 with rt_set_option("fused", 0)
-            per_frame = launches / args.steps
-            per_launch_bytes = ab_rank / per_frame
-            avg_launch_s = kernel_ms / 1e3 / launches
+        full = [x for x in launch_ms if x[0] == main_size]
+        if use_events and full:
+            # launches of ONE shape only (fpl frames each); this rank's share of their algorithmic bytes over
+            # their own kernel time. Bytes per launch: the mean over the timed poses x fpl frames.
+            ab_rank = algorithmic_bytes(mine, f, 0)["trace_kernel"]
+            per_launch_bytes = ab_rank / args.steps * main_size
+            avg_launch_s = sum(x[1] for x in full) / len(full) / 1e3
             achieved = per_launch_bytes / avg_launch_s / 1e9
-            traffic = None
-            tj = ROOT / "profiles" / "hbm_traffic.json"
-            if tj.exists():
-                tr = json.load(open(tj))
-                if tr.get("workload") == args.workload and world == 1:
-                    traffic = tr.get("hbm_bytes_per_launch")
             roofline = {"bound": "hbm", "kernel": "k_trace_level", "achieved": round(achieved, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
-                        "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": launches,
-                        "launches_per_frame": round(per_frame, 3),
-                        # frames in flight: launches of successive frames overlap, so one launch does not have
-                        # the chip to itself; all launches together move the timed region's algorithmic bytes
-                        # in the timed region's wall time
-                        "frames_in_flight": renderer.flight,
-                        "machine_achieved": round(ab_rank * args.steps / elapsed / 1e9, 2),
-                        "machine_frac": round(ab_rank * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+                        "traffic": None, "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                        "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": len(full),
+                        "frames_per_launch": main_size, "kernel_launches_per_frame_launch": full[0][2],
+                        "other_launches": [[x[0], round(x[1] * 1e3, 2)] for x in launch_ms if x[0] != main_size],
+                        "launches_in_flight": renderer.flight,
+                        "note": "HBM is the roofline SURVEY.md 8(d) prescribes, but not the ceiling that binds: the "
+                                "kernel's bytes come from L1/L2/Infinity Cache (traffic << algorithmic) and it is "
+                                "VALU-issue bound — see valu"}
+            pj = ROOT / "profiles" / f"pmc_{args.workload}.json"
+            if pj.exists() and world == 1:
+                pm = json.load(open(pj))
+                if pm.get("frames_per_launch") == main_size and pm.get("tile_log") == [
+                        int(args.tile_log[0]) if args.tile_log else (3 if fpl > 1 else (2 if renderer.flight > 1 else 1)),
+                        int(args.tile_log[1]) if args.tile_log else 3]:
+                    roofline["traffic"] = pm.get("hbm_bytes_per_launch")
+                    v = pm.get("valu_insts_per_launch")
+                    if v:
+                        peak_issue = 256 * 4 * 2.4e9 / 2   # CUs x SIMDs x clock / 2 cycles per wave64 VALU instruction
+                        roofline["valu"] = {"insts": int(v), "peak_issue_per_s": peak_issue,
+                                            "frac": round(v / avg_launch_s / peak_issue, 4),
+                                            "active_lane_frac": pm.get("valu_active_lane_frac"),
+                                            "source": f"profiles/{pj.name} (rocprofv3 --pmc, {pm.get('command', '')})"}
+                        roofline["salu_insts"] = pm.get("salu_insts_per_launch")
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(cfg, data, scenes)
+        rays_bvh = total["rays"] - total.get("rays_culled", 0)
+        per_frame = lambda v: int(round(v / args.steps))  # noqa: E731
         out = {
             "metric": "Mrays/s (primary+shadow+reflect) at 1920x1080",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "frame_ms_serial": frame_ms_serial,
+            "mrays_bvh_traversed": round(rays_bvh / elapsed / 1e6, 2),
             "config": {"workload": args.workload, "scene": data.name, "triangles": data.n_triangles,
                        "resolution": [W, H], "depth": cfg.depth, "features": cfg.features,
-                       "rays_per_frame": rays_per_frame, "rays_reference_equivalent": total["rays_ref_equiv"],
-                       "rays_primary": total["rays_primary"], "rays_shadow": total["rays_shadow"],
-                       "rays_reflect": total["rays_reflect"], "box_tests": total["box_tests"],
-                       "tri_tests": total["tri_tests"], "group_tests": total.get("group_tests", 0), "node_fetches": total["node_fetches"],
-                       "tri_fetches": total["tri_fetches"], "algorithmic_bytes_per_frame": ab["frame"],
+                       "camera": f"default trackball orbiting the scene: {n_poses} distinct poses over the timed steps, "
+                                 "one per frame (counters below: mean per frame over the timed poses)",
+                       "rays_per_frame": per_frame(total["rays"]),
+                       "rays_bvh_traversed": per_frame(rays_bvh),
+                       "rays_culled_before_traversal": per_frame(total.get("rays_culled", 0)),
+                       "rays_reference_equivalent": per_frame(total["rays_ref_equiv"]),
+                       "rays_primary": per_frame(total["rays_primary"]), "rays_shadow": per_frame(total["rays_shadow"]),
+                       "rays_reflect": per_frame(total["rays_reflect"]), "box_tests": per_frame(total["box_tests"]),
+                       "tri_tests": per_frame(total["tri_tests"]), "group_tests": per_frame(total.get("group_tests", 0)),
+                       "node_fetches": per_frame(total["node_fetches"]),
+                       "tri_fetches": per_frame(total["tri_fetches"]), "algorithmic_bytes_per_frame": per_frame(ab["frame"]),
                        "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather(overlapped" + (f",{renderer.batch}-frames-each)" if renderer.batch > 1 else ")")
                                                               if renderer.sharded else "")
-                       + (f"+{renderer.flight}-frames-in-flight" if renderer.flight > 1 else "")
+                       + (f"+{renderer.flight}-launches-in-flight" if renderer.flight > 1 else "")
                        + (f"+{fpl}-frames-per-launch" if fpl > 1 else "")
                        + ("+REHEARSAL-gloo-one-device" if rehearsal else ""),
+                       "launch_frames": sizes if len(sizes) <= 8 else {str(z): sizes.count(z) for z in sorted(set(sizes))},
                        "device": devname, "bvh_build_s": round(build_s, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -272,36 +351,57 @@ def main():
         dist.destroy_process_group()
 
 
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, data, scenes):
-    """The CPU oracle (restatement of the reference path; traces reflections twice
-    like the reference) on the same frame, all host threads. Bounded sample: every
-    `stride`-th 8-row strip of the frame so the run stays within ~10-30 s."""
+    """The CPU oracle (restatement of the reference path; traces reflections twice like the reference, OpenMP
+    `parallel for schedule(guided)` over the image rows like src/render.cpp:277-281) on the same frame, on this
+    host: ALL cores — whole frames in one call each, so every thread has rows to take, repeated until ~10 s have
+    passed — and ONE core on a bounded sample (every k-th 8-row strip, ~10 s)."""
     from oracle.cpu_oracle import Oracle
 
     orc = Oracle()
     f, p = cfg.make_features(), cfg.make_params()
     ob = orc.build(data, f)
-    cam = orc.camera(*scenes.default_camera_args(cfg.width, cfg.height))
+    W, H = cfg.width, cfg.height
+    cam = orc.camera(*scenes.default_camera_args(W, H))
     threads = orc.max_threads()
-    # calibrate on the central strip, then size the sample to ~15 s
-    mid = (cfg.height // 2 // 8) * 8
-    t0 = time.perf_counter()
-    _, _, _, c0 = orc.render(ob, cam, f, p, cfg.width, cfg.height, rows=(mid, mid + 8))
-    dt0 = max(time.perf_counter() - t0, 1e-3)
-    n_strips = cfg.height // 8
-    budget_strips = max(1, int(15.0 / dt0))
-    stride = max(1, -(-n_strips // budget_strips))
-    rays, secs, used = 0, 0.0, 0
-    for s in range(0, n_strips, stride):
+    # all cores: whole frames
+    rays, secs, frames = 0, 0.0, 0
+    while secs < 10.0 and frames < 64:
         t0 = time.perf_counter()
-        _, _, _, c = orc.render(ob, cam, f, p, cfg.width, cfg.height, rows=(s * 8, s * 8 + 8))
+        _, _, _, c = orc.render(ob, cam, f, p, W, H, want_rgb=True, threads=threads)
         secs += time.perf_counter() - t0
         rays += c.rays
+        frames += 1
+    # one core: calibrate on the central strip, then every stride-th strip for ~10 s
+    n_strips = H // 8
+    mid = (n_strips // 2) * 8
+    t0 = time.perf_counter()
+    orc.render(ob, cam, f, p, W, H, rows=(mid, mid + 8), threads=1)
+    dt0 = max(time.perf_counter() - t0, 1e-3)
+    stride = max(1, -(-n_strips // max(1, int(10.0 / dt0))))
+    rays1, secs1, used = 0, 0.0, 0
+    for s_ in range(0, n_strips, stride):
+        t0 = time.perf_counter()
+        _, _, _, c = orc.render(ob, cam, f, p, W, H, rows=(s_ * 8, s_ * 8 + 8), threads=1)
+        secs1 += time.perf_counter() - t0
+        rays1 += c.rays
         used += 1
     return {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{used} of {n_strips} 8-row strips of the same {cfg.width}x{cfg.height} frame "
-                      f"(every {stride}th), {rays} rays in {secs:.1f} s, OpenMP {threads} threads",
-            "rays": int(rays), "seconds": round(secs, 2)}
+            "value_1core": round(rays1 / secs1 / 1e6, 4), "cpu_model": cpu_model(),
+            "sample": f"all cores: {frames} whole {W}x{H} frames, one call each (OpenMP guided rows, {threads} threads), "
+                      f"{rays} reference-equivalent rays in {secs:.1f} s; 1 core: {used} of {n_strips} 8-row strips "
+                      f"(every {stride}th), {rays1} rays in {secs1:.1f} s",
+            "rays": int(rays), "seconds": round(secs, 2), "frame_ms_all_cores": round(secs / frames * 1e3, 1)}
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ EXPORTS = [
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_device_frames", "rt_render_frames", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
-    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
+    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_profile_read_launches", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
     "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp", "rt_bloom_device",
 ]
 
@@ -149,6 +149,8 @@ class Library:
                                              C.c_int32, C.c_int32, C.c_void_p]
         c.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
         c.rt_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        c.rt_profile_read_launches.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_uint64,
+                                               C.POINTER(C.c_uint64), C.c_int]
         c.rt_set_option.argtypes = [C.c_char_p, C.c_int]
         c.rt_io_last_error.restype = C.c_char_p
         c.rt_load_obj.argtypes = [C.c_char_p, C.c_int, C.POINTER(abi.LightDesc), C.c_uint32, C.POINTER(C.c_void_p)]
@@ -340,6 +342,14 @@ class Library:
         self._check(self.c.rt_profile_read(bvh.handle, C.c_void_p(stream) if stream else None, C.byref(ms),
                                            C.byref(n), 1 if reset else 0))
         return ms.value, int(n.value)
+
+    def profile_read_launches(self, bvh: Bvh, stream: int = 0, reset: bool = True, cap: int = 65536):
+        """durations (ms) of the trace-kernel launches on `stream` since the last reset, in launch order"""
+        buf = (C.c_double * cap)()
+        n = C.c_uint64()
+        self._check(self.c.rt_profile_read_launches(bvh.handle, C.c_void_p(stream) if stream else None, buf, cap,
+                                                    C.byref(n), 1 if reset else 0))
+        return [buf[i] for i in range(min(cap, int(n.value)))]
 
     def debug_div_check(self, seed: int, mode: int, n_samples: int):
         """(mismatches, fast-path samples) of the slab test's exact division vs IEEE '/' on the device."""

@@ -90,6 +90,7 @@ struct Scratch {
     std::vector<int32_t> rows_host;
     std::vector<rt::CameraPose> poses; // rt_render_device_frames: the frames' poses of the launch being enqueued
     DevBuf<uint32_t> order; // tile dispatch order (tile_order_for)
+    DevBuf<uint32_t> order_rings; // its ring counters
     DevBuf<float> samples;   // per-sample colours of multi-sample frames (k_resolve input)
     DevBuf<float> frames;    // k_trace_general: per-wave-slot recursion frames
     DevBuf<float> bloom_src; // the frame before the bloom filter
@@ -367,24 +368,24 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
     const int64_t cx = (cam.vwidth / 2) / tw - (int64_t)cam.tile_x0, cy = lrow_mid / th - (int64_t)cam.tile_y0;
     const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period };
     if (key != sc.order_key || !sc.order.p) {
+        // built on the device (k_tile_ring_*): the launched grid follows the camera, and a host-built order
+        // would put an upload + synchronisation into every launch of a moving camera
         const size_t n = (size_t)(gw * gh);
-        std::vector<uint32_t> order;
-        order.reserve(n);
         const int64_t rmax = std::max(std::max(std::llabs(cx), std::llabs(gw - 1 - cx)) * tw,
-            std::max(std::llabs(cy), std::llabs(gh - 1 - cy)) * th);
+            std::max(std::llabs(cy), std::llabs(std::min(gh, period) - 1 - cy)) * th);
         const int64_t step = std::min(tw, th);
-        // ring r holds the tiles whose pixel offset (|dx| * tw, |dy| * th) has Chebyshev length in (r - step, r]
-        std::vector<std::vector<uint32_t>> rings((size_t)(rmax / step + 2));
-        for (int64_t ty = 0; ty < gh; ty++)
-            for (int64_t tx = 0; tx < gw; tx++) {
-                const int64_t r = std::max(std::llabs(tx - cx) * tw, std::llabs(ty % period - cy) * th);
-                rings[(size_t)((r + step - 1) / step)].push_back((uint32_t)(ty * gw + tx));
-            }
-        for (const auto& ring : rings)
-            order.insert(order.end(), ring.begin(), ring.end());
-        HIP_TRY(sc.order.reserve(n));
-        HIP_TRY(hipMemcpyAsync(sc.order.p, order.data(), n * 4, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream)); // `order` is a local
+        rt::TileOrderArgs o;
+        o.gw = (uint32_t)gw, o.n_tiles = (uint32_t)n;
+        o.tw = tw, o.th = th, o.cx = cx, o.cy = cy, o.period = period, o.step = step;
+        o.n_rings = (uint32_t)(rmax / step + 2);
+        // sized for the whole tile grid once: a reallocation frees memory, which waits for the device
+        HIP_TRY(sc.order.reserve((size_t)(((cam.vwidth + tw - 1) / tw) * ((cam.n_rows + th - 1) / th))));
+        HIP_TRY(sc.order_rings.reserve((size_t)cam.vwidth + (size_t)cam.n_rows + 4u));
+        if (n > sc.order.n || o.n_rings > sc.order_rings.n)
+            return fail(RT_ERR_INVALID, "internal error: tile order scratch too small");
+        o.rings = sc.order_rings.p, o.order = sc.order.p;
+        rt::launch_tile_order(o, stream);
+        HIP_TRY(hipGetLastError());
         sc.order_key = key;
     }
     cam.order = sc.order.p;
@@ -431,6 +432,7 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
                 area_lights = true;
     a.lean = !area_lights && !f.enableNormalInterp && !f.enableTextureMapping && bvh->scene->host.spheres.empty() ? 1u : 0u;
     a.tile_cull = g_tile_cull.load() && !counters_dev ? 1u : 0u; // the counting pass traces every primary ray
+    a.tile_cull_count = g_tile_cull.load() && counters_dev ? 1u : 0u;
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
     bool rect = false;
@@ -658,7 +660,7 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "leaf_flush") == 0) {
         if (value < 1 || value > (int)rt::kLeafFlushMax)
-            return fail(RT_ERR_INVALID, "rt_set_option: leaf_flush must be in [1, 16]");
+            return fail(RT_ERR_INVALID, "rt_set_option: leaf_flush must be in [1, 36]");
         g_leaf_flush.store(value);
         return RT_OK;
     }
@@ -1265,6 +1267,25 @@ int rt_profile_read(rt_bvh* bvh, void* hip_stream, double* trace_kernel_ms, uint
         *trace_kernel_ms = ms;
     if (trace_kernel_launches)
         *trace_kernel_launches = sc.events_used;
+    if (reset)
+        sc.events_used = 0;
+    return RT_OK;
+}
+
+int rt_profile_read_launches(rt_bvh* bvh, void* hip_stream, double* launch_ms, uint64_t cap, uint64_t* n_launches,
+    int reset)
+{
+    if (!bvh || (cap && !launch_ms))
+        return fail(RT_ERR_INVALID, "rt_profile_read_launches: null argument");
+    Scratch& sc = bvh->scratch_for(hip_stream);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    for (size_t i = 0; i < sc.events_used && i < cap; i++) {
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, sc.events[i].first, sc.events[i].second));
+        launch_ms[i] = t;
+    }
+    if (n_launches)
+        *n_launches = sc.events_used;
     if (reset)
         sc.events_used = 0;
     return RT_OK;

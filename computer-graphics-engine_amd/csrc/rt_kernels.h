@@ -64,6 +64,7 @@ struct LevelArgs {
     size_t level_stride;      // floats between the `direct` planes of consecutive levels
     uint32_t merge_next;      // 1: trace a level's first shadow rays together with the next level's reflection rays
     uint32_t tile_cull;       // 1: primary tiles that cannot reach the scene bounds skip the traversal
+    uint32_t tile_cull_count; // counting pass: 1 = count (and still trace) the primary rays tile_cull would skip
     uint32_t lean;            // 1: point lights only (or soft shadows off), triangles only, no normal interpolation /
                               //    textures: the lean kernel variant renders it
     RaySoA out;
@@ -134,6 +135,15 @@ struct IntersectArgs {
     rt_counters* counters;
 };
 
+// Dispatch order of the launched tile grid (k_tile_ring_*): rings around (cx, cy), measured in pixels
+struct TileOrderArgs {
+    uint32_t gw, n_tiles; // launched grid width in tiles, tiles in it
+    int64_t tw, th, cx, cy, period, step;
+    uint32_t n_rings;
+    uint32_t* rings; // n_rings counters (scratch)
+    uint32_t* order; // out: launch position -> tile index
+};
+
 extern uint32_t g_lds_pad;
 #if defined(RT_DIAG) && RT_DIAG == 2
 void set_diag_leaf(const float4* p);
@@ -142,6 +152,7 @@ uint32_t trace_level_groups(const LevelArgs& a); // workgroups launch_trace_leve
 void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s);
 uint32_t trace_general_waves(const LevelArgs& a); // persistent waves of launch_trace_general (frame stacks are per wave slot)
 void launch_trace_general(const LevelArgs& a, bool count, hipStream_t s);
+void launch_tile_order(const TileOrderArgs& a, hipStream_t s);
 void launch_fold(const FoldArgs& a, hipStream_t s);
 void launch_resolve(const ResolveArgs& a, hipStream_t s);
 void launch_bloom(const BloomArgs& a, hipStream_t s);

@@ -203,7 +203,7 @@ RT_DEV uint32_t wave_sum(uint32_t v)
 }
 
 struct RayCounts {
-    uint32_t closest = 0, shadow = 0, hits = 0, queued = 0;
+    uint32_t closest = 0, shadow = 0, hits = 0, queued = 0, culled = 0;
 };
 
 RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCounts& rc, int32_t level, uint32_t lane)
@@ -212,6 +212,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
     const uint32_t closest = wave_sum(rc.closest), shadow = wave_sum(rc.shadow);
     const uint32_t hits = wave_sum(rc.hits), queued = wave_sum(rc.queued);
     const uint32_t node_fetch = wave_sum(lc.node_fetch), tri_fetch = wave_sum(lc.tri_fetch), grp = wave_sum(lc.grp);
+    const uint32_t culled = wave_sum(rc.culled);
     if (lane == 0) {
         auto add = [](uint64_t* p, uint64_t v) {
             if (v)
@@ -229,6 +230,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
         add(&out->hits_shaded, hits);
         add(&out->rays_queued, queued);
         add(&out->group_tests, grp);
+        add(&out->rays_culled, culled);
     }
 }
 
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     const bool prune = (flags & F_NO_PRUNE) == 0;
 
     // ---- fetch this lane's ray ------------------------------------------------
-    bool active = false;
+    bool active = false, would_cull = false;
     RayL ray;
     ray.o = mk(0, 0, 0), ray.d = mk(0, 0, -1);
     float t = kFltMax;
@@ -801,6 +803,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
                 a.state[item] = 0u; // every primary ray of the tile misses: vec3(0) (render.cpp:149-150)
             return;
         }
+        if (COUNT && a.tile_cull_count && a.level == 0 && cam.spp == 1 && cam.dof_n == 0 && use_bvh && prune
+            && sv.prune_ok != 0u)
+            would_cull = tile_misses_scene(cam, sv, active, x, y); // counted, and traced all the same
         if (active) {
             ray = camera_ray(cam, x, y);
             pixel = (uint32_t)y * (uint32_t)cam.vwidth + (uint32_t)x;  // RNG key of the light samples
@@ -864,7 +869,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
 #endif
     RayCounts rc;
     if (COUNT && active)
-        rc.closest = 1;
+        rc.closest = 1, rc.culled = would_cull ? 1u : 0u;
     __shared__ WaveLds lds[kBlock / 64];
     WaveLds& wl = lds[threadIdx.x >> 6];
 
@@ -1228,6 +1233,53 @@ __global__ __launch_bounds__(256) void k_div_check(uint32_t seed, uint32_t mode,
     atomicAdd(&out[1], fast);
 }
 
+// Dispatch order of the launched tiles, built on the device (no host round trip when the launched grid
+// changes with the camera): rings around the centre of the launched grid, innermost first, as a counting
+// sort — ring sizes (k_tile_ring_count), exclusive scan (k_tile_ring_scan), scatter (k_tile_ring_scatter).
+// The order inside a ring is whatever the atomics give: a scheduling choice, results do not depend on it.
+RT_DEV uint32_t tile_ring(const TileOrderArgs& a, uint32_t tile)
+{
+    const int64_t ty = tile / a.gw, tx = tile - (uint32_t)ty * a.gw;
+    const int64_t dx = tx - a.cx, dy = ty % a.period - a.cy;
+    const int64_t r = max((dx < 0 ? -dx : dx) * a.tw, (dy < 0 ? -dy : dy) * a.th);
+    const int64_t q = (r + a.step - 1) / a.step;
+    return (uint32_t)(q < (int64_t)a.n_rings - 1 ? q : (int64_t)a.n_rings - 1);
+}
+__global__ __launch_bounds__(256) void k_tile_ring_count(const TileOrderArgs a)
+{
+    const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
+    if (tile < a.n_tiles)
+        atomicAdd(&a.rings[tile_ring(a, tile)], 1u);
+}
+__global__ __launch_bounds__(1024) void k_tile_ring_scan(const TileOrderArgs a)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (a.n_rings + 1023u) / 1024u, b = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < b + per && i < a.n_rings; i++)
+        sum += a.rings[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = b; i < b + per && i < a.n_rings; i++) {
+        const uint32_t c = a.rings[i];
+        a.rings[i] = run;
+        run += c;
+    }
+}
+__global__ __launch_bounds__(256) void k_tile_ring_scatter(const TileOrderArgs a)
+{
+    const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
+    if (tile < a.n_tiles)
+        a.order[atomicAdd(&a.rings[tile_ring(a, tile)], 1u)] = tile;
+}
+
 uint32_t grid_for_waves(uint64_t waves) { return (uint32_t)((waves + (kBlock / 64) - 1) / (kBlock / 64)); }
 
 uint64_t camera_waves(const CameraArgs& c)
@@ -1302,6 +1354,17 @@ void launch_trace_general(const LevelArgs& a, bool count, hipStream_t s)
         hipLaunchKernelGGL(k_trace_general<true>, dim3(grid), dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(k_trace_general<false>, dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+void launch_tile_order(const TileOrderArgs& a, hipStream_t s)
+{
+    if (a.n_tiles == 0)
+        return;
+    (void)hipMemsetAsync(a.rings, 0, (size_t)a.n_rings * sizeof(uint32_t), s);
+    const uint32_t grid = (a.n_tiles + 255u) / 256u;
+    hipLaunchKernelGGL(k_tile_ring_count, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_tile_ring_scan, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_tile_ring_scatter, dim3(grid), dim3(256), 0, s, a);
 }
 
 void launch_fold(const FoldArgs& a, hipStream_t s)

@@ -47,6 +47,20 @@ inline Vec3 normalize(Vec3 v)
 }
 
 // ---- tinyobjloader's number parser (tiny_obj_loader.h:866-996), restated -------
+// The digit-by-digit double accumulation below IS the parity contract for every parsed float (a different
+// but equally correct parser rounds differently), so this function follows tinyobjloader's tryParseDouble
+// closely — same accumulation order, same names. tinyobjloader is
+//   Copyright (c) 2012-Present, Syoyo Fujita and many contributors, The MIT License (MIT):
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without
+//   limitation the rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the
+//   Software, and to permit persons to whom the Software is furnished to do so, subject to the following
+//   conditions: The above copyright notice and this permission notice shall be included in all copies or
+//   substantial portions of the Software. THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS
+//   OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE
+//   AND NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR
+//   OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION
+//   WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
 bool try_parse_double(const char* s, const char* s_end, double* result)
 {
     if (s >= s_end)

@@ -186,6 +186,8 @@ typedef struct rt_counters {
     uint64_t hits_shaded;    /* closest hits whose attributes were resolved and shaded */
     uint64_t rays_queued;    /* reflection rays written to a device queue */
     uint64_t group_tests;    /* conservative ray / triangle-group box tests of the leaf phase (pruned policy only) */
+    uint64_t rays_culled;    /* primary rays (counted in `rays`) of tiles the timed launch ends in its prologue or never
+                              * launches: their ray pyramid misses the scene bounds, so they never touch the BVH */
 } rt_counters;
 
 typedef struct rt_scene rt_scene; /* opaque */
@@ -331,6 +333,10 @@ int rt_write_bmp(const char* path, const float* rgb, int32_t width, int32_t heig
 int rt_profile_enable(rt_bvh* bvh, int enable);
 int rt_profile_read(rt_bvh* bvh, void* hip_stream, double* trace_kernel_ms, uint64_t* trace_kernel_launches,
                     int reset);
+/* The same events one by one: launch_ms[i] = duration of the i-th trace-kernel launch on `hip_stream` since the
+ * last reset (the first `cap` of them), *n_launches = how many there were. */
+int rt_profile_read_launches(rt_bvh* bvh, void* hip_stream, double* launch_ms, uint64_t cap, uint64_t* n_launches,
+                             int reset);
 
 /* -- Device self-check of the slab test's reciprocal-based exact division
  *    (csrc/rt_device.h div_by_ray) against the device's own IEEE '/', on

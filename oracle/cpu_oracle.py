@@ -209,6 +209,34 @@ class Oracle:
         self.lib.orc_acquire_texel(bvh.scene_handle, texture, _f2(tc), C.byref(features), out)
         return np.array(out[:], np.float32)
 
+    # -- area-light samplers with the rand() draws as arguments (raw 31-bit values), src/light.cpp:19-45
+    def sample_segment_light(self, v4x3, r31, index, sample_size):
+        v = np.ascontiguousarray(v4x3, np.float32)
+        pos, col = (C.c_float * 3)(), (C.c_float * 3)()
+        self.lib.orc_sample_segment_light(v.ctypes.data_as(C.c_void_p), C.c_uint32(int(r31)), C.c_float(index),
+                                          C.c_float(sample_size), pos, col)
+        return np.array(pos[:], np.float32), np.array(col[:], np.float32)
+
+    def sample_parallelogram_light(self, v7x3, r31_h, r31_v, hor_index, ver_index, size_a, size_b):
+        v = np.ascontiguousarray(v7x3, np.float32)
+        pos, col = (C.c_float * 3)(), (C.c_float * 3)()
+        self.lib.orc_sample_parallelogram_light(v.ctypes.data_as(C.c_void_p), C.c_uint32(int(r31_h)),
+                                                C.c_uint32(int(r31_v)), C.c_float(hor_index), C.c_float(ver_index),
+                                                C.c_float(size_a), C.c_float(size_b), pos, col)
+        return np.array(pos[:], np.float32), np.array(col[:], np.float32)
+
+    def weights_gaussian(self, sigma):
+        """weightsGaussian (src/render.cpp:198-210) → 3x3, [i + 1][k + 1]"""
+        out = (C.c_float * 9)()
+        self.lib.orc_weights_gaussian(C.c_float(sigma), out)
+        return np.array(out[:], np.float32).reshape(3, 3)
+
+    def get_intersection(self, ray, D, normal):
+        """getIntersection (src/render.cpp:238-243)"""
+        out = (C.c_float * 3)()
+        self.lib.orc_get_intersection(C.byref(ray), C.c_float(D), _f3(normal), out)
+        return np.array(out[:], np.float32)
+
     def intersect_triangle(self, v0, v1, v2, ray: "abi.Ray"):
         r = abi.Ray.from_buffer_copy(ray)
         h = self.lib.orc_intersect_triangle(_f3(v0), _f3(v1), _f3(v2), C.byref(r))
@@ -374,3 +402,41 @@ class Reference:
 
     def radians(self, deg):
         return float(self.lib.ref_glm_radians(deg))
+
+    # -- round 2: area-light samplers (rand() replayed), weightsGaussian, getIntersection, BMP bytes
+    def sample_segment_light(self, v4x3, seed, index, sample_size):
+        """sampleSegmentLight (src/light.cpp:19-26) after srand(seed) → (pos, col, the rand() value it drew)"""
+        v = np.ascontiguousarray(v4x3, np.float32)
+        pos, col, drawn = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_int32 * 1)()
+        self.lib.ref_sample_segment_light(v.ctypes.data_as(C.c_void_p), C.c_uint(int(seed)), C.c_float(index),
+                                          C.c_float(sample_size), pos, col, drawn)
+        return np.array(pos[:], np.float32), np.array(col[:], np.float32), int(drawn[0])
+
+    def sample_parallelogram_light(self, v7x3, seed, hor_index, ver_index, size_a, size_b):
+        """sampleParallelogramLight (src/light.cpp:30-45) after srand(seed) → (pos, col, its two rand() values)"""
+        v = np.ascontiguousarray(v7x3, np.float32)
+        pos, col, drawn = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_int32 * 2)()
+        self.lib.ref_sample_parallelogram_light(v.ctypes.data_as(C.c_void_p), C.c_uint(int(seed)), C.c_float(hor_index),
+                                                C.c_float(ver_index), C.c_float(size_a), C.c_float(size_b), pos, col,
+                                                drawn)
+        return np.array(pos[:], np.float32), np.array(col[:], np.float32), int(drawn[0]), int(drawn[1])
+
+    def rand_max(self) -> int:
+        return int(self.lib.ref_rand_max())
+
+    def weights_gaussian(self, sigma):
+        out = (C.c_float * 9)()
+        self.lib.ref_weights_gaussian(C.c_float(sigma), out)
+        return np.array(out[:], np.float32).reshape(3, 3)
+
+    def get_intersection(self, ray, D, normal):
+        out = (C.c_float * 3)()
+        self.lib.ref_get_intersection(C.byref(ray), C.c_float(D), _f3(normal), out)
+        return np.array(out[:], np.float32)
+
+    def write_bmp(self, path, frame: np.ndarray) -> int:
+        """Screen::writeBitmapToFile's conversion + the vendored stbi_write_bmp (oracle/ref_bmp.cpp);
+        frame = (H, W, 3) fp32 in Screen::m_textureData order (row 0 = top of the image)"""
+        frame = np.ascontiguousarray(frame, np.float32)
+        return int(self.lib.ref_write_bmp(str(path).encode(), frame.ctypes.data_as(C.c_void_p), frame.shape[1],
+                                          frame.shape[0]))

@@ -9,14 +9,21 @@
  *   tinyobjloader, stb_image, fmt), src/shading.cpp, src/interpolate.cpp,
  *   src/texture.cpp, src/light.cpp, src/bounding_volume_hierarchy.cpp,
  *   src/bvh_interface.cpp.
+ *   src/bvh_interface.cpp, src/render.cpp (compiles with the same include path:
+ *   render.h / screen.h / trackball.h pull in no GL header).
  * NOT built / NOT loaded: prebuilt/libIntersect_* (prebuilt machine code),
- * src/draw.cpp, src/screen.cpp, framework/src/{window,trackball}.cpp (need
- * GL/glu.h, absent), src/render.cpp (needs those). The library therefore has
- * unresolved symbols (draw*, intersectRayWith*); it is loaded with RTLD_LAZY
- * and this harness only calls functions that never reach them:
+ * src/draw.cpp, src/screen.cpp, framework/src/{window,trackball}.cpp (they
+ * include framework/opengl_includes.h → GL/glu.h, absent from this image). The
+ * library therefore has unresolved symbols (draw*, intersectRayWith*, Screen::*,
+ * Trackball::*); it is loaded with RTLD_LAZY and this harness only calls
+ * functions that never reach them:
  *   - scene loading, BVH *construction* (no traversal), shading, reflection
  *     ray, barycentrics, interpolation, texel fetch, the point-light loop of
- *     computeLightContribution with shadows off.
+ *     computeLightContribution with shadows off, the two area-light samplers
+ *     (src/light.cpp:19-45, rand() replayed through srand), weightsGaussian and
+ *     getIntersection of src/render.cpp.
+ * oracle/ref_bmp.cpp (its own TU) compiles the vendored stb_image_write.h by path
+ * for the BMP byte layout of Screen::writeBitmapToFile (src/screen.cpp:49-60).
  * The camera functions below are the harness's own use of the vendored glm
  * (framework/src/trackball.cpp itself cannot be built): they pin the glm
  * operation order that the oracle restates by hand.
@@ -31,6 +38,7 @@
 #include "bvh_interface.h"
 #include "interpolate.h"
 #include "light.h"
+#include "render.h"
 #include "scene.h"
 #include "shading.h"
 #include "texture.h"
@@ -38,6 +46,15 @@
 #include <glm/gtc/quaternion.hpp>
 
 #include "../include/rt_whitted.h"
+
+// Definitions with external linkage in the reference whose headers do not declare them (light.h declares
+// three-argument samplers that nothing defines; render.h omits getIntersection): declared here with the
+// signatures of the definitions at src/light.cpp:19,30 and src/render.cpp:238.
+void sampleSegmentLight(const SegmentLight& segmentLight, glm::vec3& position, glm::vec3& color, float index,
+    float sampleSize);
+void sampleParallelogramLight(const ParallelogramLight& parallelogramLight, glm::vec3& position, glm::vec3& color,
+    float horizontalIndex, float verticalIndex, float sampleSizeA, float sampleSizeB);
+glm::vec3 getIntersection(const Ray& ray, const Plane& plane);
 
 static Features toFeatures(const rt_features* f)
 {
@@ -247,6 +264,53 @@ int ref_light_contribution_noshadow(Scene* s, const rt_features* f, const rt_ray
     glm::vec3 c = computeLightContribution(*s, *it->second, feat, makeRay(ray), makeHit(normal, m));
     memcpy(out, &c, 12);
     return 0;
+}
+
+// ---- area-light samplers (src/light.cpp:19-45). They draw from the process-global rand():
+// srand(seed) → record the draws → srand(seed) again → call the reference, so the caller knows
+// exactly which rand() values the reference consumed (glibc: RAND_MAX = 2147483647).
+void ref_sample_segment_light(const float v[4][3], unsigned seed, float index, float sampleSize, float pos[3],
+    float col[3], int32_t* drawn)
+{
+    SegmentLight L { g3(v[0]), g3(v[1]), g3(v[2]), g3(v[3]) };
+    srand(seed);
+    drawn[0] = rand();
+    srand(seed);
+    glm::vec3 p, c;
+    sampleSegmentLight(L, p, c, index, sampleSize);
+    memcpy(pos, &p, 12);
+    memcpy(col, &c, 12);
+}
+void ref_sample_parallelogram_light(const float v[7][3], unsigned seed, float horizontalIndex, float verticalIndex,
+    float sampleSizeA, float sampleSizeB, float pos[3], float col[3], int32_t* drawn)
+{
+    ParallelogramLight L { g3(v[0]), g3(v[1]), g3(v[2]), g3(v[3]), g3(v[4]), g3(v[5]), g3(v[6]) };
+    srand(seed);
+    drawn[0] = rand();
+    drawn[1] = rand();
+    srand(seed);
+    glm::vec3 p, c;
+    sampleParallelogramLight(L, p, c, horizontalIndex, verticalIndex, sampleSizeA, sampleSizeB);
+    memcpy(pos, &p, 12);
+    memcpy(col, &c, 12);
+}
+int ref_rand_max(void) { return RAND_MAX; }
+
+// ---- src/render.cpp: weightsGaussian (:198-210), getIntersection (:238-243) ----
+void ref_weights_gaussian(float sigma, float out[9])
+{
+    const glm::mat3 m = weightsGaussian(sigma);
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++)
+            out[3 * i + k] = m[i][k];
+}
+void ref_get_intersection(const rt_ray* ray, float D, const float normal[3], float out[3])
+{
+    Plane pl;
+    pl.D = D;
+    pl.normal = g3(normal);
+    const glm::vec3 p = getIntersection(makeRay(ray), pl);
+    memcpy(out, &p, 12);
 }
 
 // ---- camera math through the vendored glm (harness restatement of

@@ -606,6 +606,29 @@ inline uint32_t rand31(uint32_t seed, uint32_t pixel, uint32_t level, uint32_t l
 // (float)rand() / RAND_MAX, RAND_MAX = 2147483647 → 2147483648.0f
 inline float rand01(uint32_t r31) { return (float)(int32_t)r31 / 2147483648.0f; }
 
+// sampleSegmentLight, src/light.cpp:19-26, with its rand() draw as an argument:
+// r = (float)rand() / RAND_MAX. v = endpoint0, endpoint1, color0, color1.
+inline void sampleSegmentLight(const V3* v, float r, float index, float sampleSize, V3& position, V3& color)
+{
+    float weight = (index + r) / sampleSize;
+    position = (v[1] - v[0]) * weight + v[0];
+    color = weight * v[3] + (1 - weight) * v[2];
+}
+// sampleParallelogramLight, src/light.cpp:30-45, with its two rand() draws as arguments.
+// v = v0, edge01, edge02, color0..color3.
+inline void sampleParallelogramLight(const V3* v, float horRandom, float verRandom, float horizontalIndex,
+    float verticalIndex, float sampleSizeA, float sampleSizeB, V3& position, V3& color)
+{
+    float horWeight = (horizontalIndex + horRandom) / sampleSizeA;
+    float verWeight = (verticalIndex + verRandom) / sampleSizeB;
+    V3 horVector = horWeight * v[1];
+    V3 verVector = verWeight * v[2];
+    position = v[0] + horVector + verVector;
+    V3 bottomColor = horWeight * v[4] + (1 - horWeight) * v[3];
+    V3 topColor = horWeight * v[6] + (1 - horWeight) * v[5];
+    color = verWeight * topColor + (1 - verWeight) * bottomColor;
+}
+
 struct TraceCtx {
     const orc_bvh* bvh;
     rt_features f;
@@ -659,11 +682,9 @@ V3 computeLightContribution(TraceCtx& cx, const Ray& ray, const HitInfo& hitInfo
                 V3 color = v3(0, 0, 0);
                 float sampleSize = (float)cx.params.segment_n;
                 for (int i = 0; (float)i < sampleSize; i++) {
-                    // sampleSegmentLight (:19-26)
                     float r = rand01(rand31(cx.params.seed, cx.pixel, level, (uint32_t)li, (uint32_t)i, 0));
-                    float weight = ((float)i + r) / sampleSize;
-                    V3 position = (L.v[1] - L.v[0]) * weight + L.v[0];
-                    V3 colorOfLight = weight * L.v[3] + (1 - weight) * L.v[2];
+                    V3 position, colorOfLight;
+                    sampleSegmentLight(L.v, r, (float)i, sampleSize, position, colorOfLight);
                     float visibility = testVisibilityLightSample(cx, position, ray, hitInfo);
                     V3 thisColor = computeShading(position, colorOfLight, cx.f, ray, hitInfo);
                     color = color + thisColor * visibility;
@@ -678,18 +699,12 @@ V3 computeLightContribution(TraceCtx& cx, const Ray& ray, const HitInfo& hitInfo
                 int n = cx.params.parallelogram_n;
                 for (int i = 0; (float)i < sampleSizeA; i++) {
                     for (int k = 0; (float)k < sampleSizeB; k++) {
-                        // sampleParallelogramLight (:30-45)
                         uint32_t s = (uint32_t)(i * n + k);
                         float horRandom = rand01(rand31(cx.params.seed, cx.pixel, level, (uint32_t)li, s, 0));
                         float verRandom = rand01(rand31(cx.params.seed, cx.pixel, level, (uint32_t)li, s, 1));
-                        float horWeight = ((float)i + horRandom) / sampleSizeA;
-                        float verWeight = ((float)k + verRandom) / sampleSizeB;
-                        V3 horVector = horWeight * L.v[1];
-                        V3 verVector = verWeight * L.v[2];
-                        V3 position = L.v[0] + horVector + verVector;
-                        V3 bottomColor = horWeight * L.v[4] + (1 - horWeight) * L.v[3];
-                        V3 topColor = horWeight * L.v[6] + (1 - horWeight) * L.v[5];
-                        V3 colorOfLight = verWeight * topColor + (1 - verWeight) * bottomColor;
+                        V3 position, colorOfLight;
+                        sampleParallelogramLight(L.v, horRandom, verRandom, (float)i, (float)k, sampleSizeA, sampleSizeB,
+                            position, colorOfLight);
                         float visibility = testVisibilityLightSample(cx, position, ray, hitInfo);
                         V3 thisColor = computeShading(position, colorOfLight, cx.f, ray, hitInfo);
                         color = color + thisColor * visibility;
@@ -1336,6 +1351,40 @@ int orc_intersect_sphere(const float center[3], float radius, rt_ray* ray, float
     if (normal_out)
         normal_out[0] = h.normal.x, normal_out[1] = h.normal.y, normal_out[2] = h.normal.z;
     return hit;
+}
+// single-function probes of the area-light samplers (the rand() draws are arguments: the raw 31-bit
+// values), weightsGaussian and getIntersection — pinned against the reference in tests/test_oracle_pins.py
+void orc_sample_segment_light(const float v[4][3], uint32_t r31, float index, float sampleSize, float pos[3],
+    float col[3])
+{
+    const V3 vv[4] = { v3(v[0]), v3(v[1]), v3(v[2]), v3(v[3]) };
+    V3 p, c;
+    sampleSegmentLight(vv, rand01(r31), index, sampleSize, p, c);
+    pos[0] = p.x, pos[1] = p.y, pos[2] = p.z, col[0] = c.x, col[1] = c.y, col[2] = c.z;
+}
+void orc_sample_parallelogram_light(const float v[7][3], uint32_t r31_h, uint32_t r31_v, float horizontalIndex,
+    float verticalIndex, float sampleSizeA, float sampleSizeB, float pos[3], float col[3])
+{
+    const V3 vv[7] = { v3(v[0]), v3(v[1]), v3(v[2]), v3(v[3]), v3(v[4]), v3(v[5]), v3(v[6]) };
+    V3 p, c;
+    sampleParallelogramLight(vv, rand01(r31_h), rand01(r31_v), horizontalIndex, verticalIndex, sampleSizeA, sampleSizeB,
+        p, c);
+    pos[0] = p.x, pos[1] = p.y, pos[2] = p.z, col[0] = c.x, col[1] = c.y, col[2] = c.z;
+}
+void orc_weights_gaussian(float sigma, float out[9])
+{
+    float w[3][3];
+    weightsGaussian(sigma, w);
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++)
+            out[3 * i + k] = w[i][k];
+}
+void orc_get_intersection(const rt_ray* ray, float D, const float normal[3], float out[3])
+{
+    Ray r;
+    r.origin = v3(ray->origin), r.direction = v3(ray->direction), r.t = ray->t;
+    const V3 p = getIntersection(r, PlaneDN { D, v3(normal) });
+    out[0] = p.x, out[1] = p.y, out[2] = p.z;
 }
 uint32_t orc_rand31(uint32_t seed, uint32_t pixel, uint32_t level, uint32_t light, uint32_t sample, uint32_t dim)
 {
