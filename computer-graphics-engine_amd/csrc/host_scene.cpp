@@ -298,6 +298,7 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
     std::vector<uint32_t> leaf_dev_beg(nodes.size(), 0);
     this->records.clear();
     this->records.reserve(n);
+    ref_leaf_of.clear(), wide_leaf_box.clear();
     {
         std::vector<int32_t> stack { root };
         while (!stack.empty()) {
@@ -306,8 +307,14 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
             const RefNode& nd = nodes[i];
             if (nd.leaf) {
                 leaf_dev_beg[i] = (uint32_t)this->records.size();
-                for (int32_t p = nd.beg; p < nd.end; p++)
+                LeafBox lb;
+                memset(&lb, 0, sizeof(lb));
+                memcpy(lb.lo, nd.lo, 12), memcpy(lb.hi, nd.hi, 12);
+                for (int32_t p = nd.beg; p < nd.end; p++) {
                     this->records.push_back(flat[p]);
+                    ref_leaf_of.push_back((uint32_t)wide_leaf_box.size());
+                }
+                wide_leaf_box.push_back(lb);
             } else {
                 stack.push_back(nd.left);
                 stack.push_back(nd.right);
@@ -434,6 +441,11 @@ std::string HostBvh::build(const HostScene& scene, bool sah_binning)
     // entry (rt_device.h pack_entry) relies on it
     if (pairs.size() > (1u << 15))
         return "internal error: more than 32768 internal nodes";
+    // the wide tree: triangles only, and a root that is an internal node (a leaf root is never box-tested,
+    // bvh.cpp:313 — such scenes are tiny and stay on the exact-topology traversal)
+    wide_ok = false;
+    if (scene.spheres.empty() && !nodes[root].leaf && bounds_finite)
+        build_wide();
     return "";
 }
 

@@ -57,6 +57,15 @@ struct HostBvh {
     // records[grouped_src[i]] (0xffffffff = padding)
     std::vector<GroupRecord> groups;
     std::vector<uint32_t> grouped_src;
+    // the wide tree over the triangles (rt_layout.h WideNode; host_wide.cpp); wide_ok false: not built
+    std::vector<WideNode> wide_nodes;
+    std::vector<uint32_t> wide_slot_src; // slot -> index into `records` (0xffffffff = padding)
+    std::vector<uint32_t> wide_index;    // per slot: index into `records` (0 for padding)
+    std::vector<LeafBox> wide_leaf_box;  // per reference leaf, in visit order
+    std::vector<uint32_t> ref_leaf_of;   // per entry of `records`: its reference leaf
+    bool wide_ok = false;
+    uint32_t wide_depth = 0;
+    void build_wide(); // host_wide.cpp; needs records
     uint32_t root_ref = 0, root_cnt = 0; // root_cnt: count word (rt_layout.h)
     int num_levels = 0, num_leaves = 0;
     uint32_t max_leaf = 0;

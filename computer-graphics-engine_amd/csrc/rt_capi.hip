@@ -29,6 +29,8 @@ std::mutex g_host_call_mu;
 std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
+// rt_set_option("wide", 0): traverse the reference-topology tree only (the wide tree stays built)
+std::atomic<int> g_wide { 1 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
 std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
@@ -135,6 +137,10 @@ struct rt_bvh {
     DevBuf<rt::PrimRecord> prims, prims_flat;
     DevBuf<rt::LeafRecord> leaf, leaf_flat, leaf_grouped;
     DevBuf<rt::GroupRecord> groups;
+    DevBuf<rt::WideNode> wide_nodes;
+    DevBuf<rt::LeafRecord> wide_leaf;
+    DevBuf<uint32_t> wide_index, wide_ref_leaf;
+    DevBuf<rt::LeafBox> wide_leaf_box;
 #ifdef RT_DIAG
     DevBuf<rt::NodePair> diag_nodes;
     DevBuf<rt::LeafRecord> diag_leaf;
@@ -183,6 +189,15 @@ struct rt_bvh {
             memset(v.scene_lo, 0, 12), memset(v.scene_hi, 0, 12);
         }
         v.leaf_flush = (uint32_t)g_leaf_flush.load();
+        v.wide_nodes = wide_nodes.p;
+        v.wide_leaf = reinterpret_cast<const float4*>(wide_leaf.p);
+        v.wide_index = wide_index.p;
+        v.wide_ref_leaf = wide_ref_leaf.p;
+        v.wide_leaf_box = wide_leaf_box.p;
+        v.wide_n_nodes = (uint32_t)host.wide_nodes.size();
+        v.wide_n_groups = (uint32_t)(host.wide_slot_src.size() / 4);
+        v.wide_n_ref_leaves = (uint32_t)host.wide_leaf_box.size();
+        v.wide_ok = host.wide_ok && g_wide.load() ? 1u : 0u;
         v.stamps = g_stamps;
 #ifdef RT_DIAG
         v.diag_nodes = diag_nodes.p;
@@ -658,6 +673,10 @@ int rt_set_option(const char* name, int value)
         rt::g_lds_pad = (uint32_t)value;
         return RT_OK;
     }
+    if (name && strcmp(name, "wide") == 0) {
+        g_wide.store(value != 0);
+        return RT_OK;
+    }
     if (name && strcmp(name, "leaf_flush") == 0) {
         if (value < 1 || value > (int)rt::kLeafFlushMax)
             return fail(RT_ERR_INVALID, "rt_set_option: leaf_flush must be in [1, 36]");
@@ -743,6 +762,19 @@ int rt_bvh_build(rt_scene* scene, const rt_features* features, rt_bvh** out)
                 memset(&g[i], 0, sizeof(g[i]));
         HIP_TRY(b->leaf_grouped.upload(leaf_records(g)));
         HIP_TRY(b->groups.upload(b->host.groups));
+    }
+    if (b->host.wide_ok) { // the wide tree (rt_wide.h): nodes, leaf records per slot, slot meta, reference leaf boxes
+        std::vector<rt::PrimRecord> g(b->host.wide_slot_src.size());
+        for (size_t i = 0; i < g.size(); i++)
+            if (b->host.wide_slot_src[i] != 0xffffffffu)
+                g[i] = b->host.records[b->host.wide_slot_src[i]];
+            else
+                memset(&g[i], 0, sizeof(g[i]));
+        HIP_TRY(b->wide_leaf.upload(leaf_records(g)));
+        HIP_TRY(b->wide_nodes.upload(b->host.wide_nodes));
+        HIP_TRY(b->wide_index.upload(b->host.wide_index));
+        HIP_TRY(b->wide_ref_leaf.upload(b->host.ref_leaf_of));
+        HIP_TRY(b->wide_leaf_box.upload(b->host.wide_leaf_box));
     }
 #ifdef RT_DIAG
     HIP_TRY(b->diag_nodes.upload(b->host.pairs));

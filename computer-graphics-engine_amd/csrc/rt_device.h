@@ -124,25 +124,42 @@ struct LaneCounters {
 #endif
 };
 
-// Per-wave LDS working set (10 224 B): ray table, best-key slots, the per-lane
-// deques (slot [level][lane]: conflict-free; entry = node pair index << 6 | ray
-// slot, plus the entry's distance lower bound) and the (ray, leaf) pair queue.
+// Per-wave LDS working set (10 240 B): ray table and best-key slots, shared by the two traversal engines, and
+// a union of their private parts. Exact-topology engine (rt_traverse.h): per-lane deques (slot [level][lane]:
+// conflict-free; entry = node pair index << 6 | ray slot, plus the entry's distance lower bound), the
+// (ray, leaf) pair queue and the surviving-group list. Wide engine (rt_wide.h): per-lane deques of
+// (node, ray) entries with a 16-bit lower bound each, the (ray, leaf group) queue and the mask of rays that must
+// take the exact engine.
 constexpr uint32_t kStackLevels = 16; // MAX_DEPTH = 16 levels ⇒ at most 15 internal levels pending
 constexpr uint32_t kLeafFlushMax = 36; // largest leaf_flush threshold (SceneView::leaf_flush)
 constexpr uint32_t kLeafQueue = 164;   // < kLeafFlushMax left over + at most 128 appended per node step
+constexpr uint32_t kWideStack = 13;      // deque slots per lane; a lane that needs more sends its ray to the exact engine
+constexpr uint32_t kWideFlushMax = 28;   // largest flush threshold of the wide engine's leaf queue
+constexpr uint32_t kWideLeafQueue = 284; // < kWideFlushMax left over + at most 256 appended per node step
 struct alignas(16) WaveLds {
     float4 rayA[64]; // ox oy oz dx
     float4 rayB[64]; // dy dz t0 guard bits (RayInv::ok[0..2], all_ok)
     float4 rayC[64]; // RN(1/dx) RN(1/dy) RN(1/dz) pruning slack — RayInv, computed once per ray
     unsigned long long best[64];
-    uint32_t stack[kStackLevels][64]; // packed entries, see pack_entry()
-    uint32_t lq_ref[kLeafQueue];
-    uint32_t lq_cw[kLeafQueue]; // count word of the leaf (rt_layout.h); lq_ref holds ref | ray slot << 26
-    float lq_lb[kLeafQueue];
-    uint32_t xfer[64];          // work-stealing hand-over slots
-    uint32_t surv[80];          // leaf phase: surviving (pair, group) entries, < 16 left over + 64 new
+    uint32_t xfer[64]; // work-stealing hand-over slots
+    union {
+        struct { // exact-topology engine
+            uint32_t stack[kStackLevels][64]; // packed entries, see pack_entry()
+            uint32_t lq_ref[kLeafQueue];
+            uint32_t lq_cw[kLeafQueue]; // count word of the leaf (rt_layout.h); lq_ref holds ref | ray slot << 26
+            float lq_lb[kLeafQueue];
+            uint32_t surv[80];          // leaf phase: surviving (pair, group) entries, < 16 left over + 64 new
+        };
+        struct { // wide engine
+            uint32_t wstack[kWideStack][64];    // node index << 6 | ray slot
+            uint16_t wstack_lb[kWideStack][64]; // the entry's lower bound: top 16 bits of the float, i.e. rounded down
+            uint32_t wlq[kWideLeafQueue];       // leaf group index | (triangles - 1) << 24 | ray slot << 26
+            uint16_t wxfer_lb[64];
+            uint32_t wfallback[2];              // ray slots that must be traced by the exact engine
+        };
+    };
 };
-static_assert(sizeof(WaveLds) == 10224, "WaveLds"); // one wave per workgroup: 16 of them fit a CU's 160 KiB (163 584 B)
+static_assert(sizeof(WaveLds) <= 10240, "WaveLds"); // one wave per workgroup: 16 of them fit a CU's 160 KiB (163 840 B)
 
 // A deque entry in 32 bits: [31:21] lower bound, [20:6] node pair index, [5:0] ray slot.
 // MAX_DEPTH = 16 levels caps a tree at 32 767 internal nodes (15 bits). The bound keeps

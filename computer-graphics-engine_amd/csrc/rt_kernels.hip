@@ -1245,11 +1245,32 @@ RT_DEV uint32_t tile_ring(const TileOrderArgs& a, uint32_t tile)
     const int64_t q = (r + a.step - 1) / a.step;
     return (uint32_t)(q < (int64_t)a.n_rings - 1 ? q : (int64_t)a.n_rings - 1);
 }
+// One atomic per (wave, ring) instead of one per tile: the 64 consecutive tiles of a wave lie in a handful of
+// rings, and hundreds of thousands of single adds to a few hundred counters serialise in their L2 channels
+// (~50 ns each). `base`: what the leader's add returned (scatter) — lanes of the same ring take consecutive places.
+RT_DEV uint32_t ring_add(uint32_t* rings, bool valid, uint32_t ring)
+{
+    uint32_t place = 0;
+    uint64_t todo = ballot(valid);
+    while (todo) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t r0 = read_lane(ring, leader);
+        const uint64_t same = ballot(valid && ring == r0) & todo;
+        uint32_t base = 0;
+        if (lane_id() == leader)
+            base = atomicAdd(&rings[r0], (uint32_t)__builtin_popcountll(same));
+        base = read_lane(base, leader);
+        if (valid && ring == r0)
+            place = base + prefix_count(same);
+        todo &= ~same;
+    }
+    return place;
+}
 __global__ __launch_bounds__(256) void k_tile_ring_count(const TileOrderArgs a)
 {
     const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
-    if (tile < a.n_tiles)
-        atomicAdd(&a.rings[tile_ring(a, tile)], 1u);
+    const bool valid = tile < a.n_tiles;
+    ring_add(a.rings, valid, valid ? tile_ring(a, tile) : 0u);
 }
 __global__ __launch_bounds__(1024) void k_tile_ring_scan(const TileOrderArgs a)
 {
@@ -1276,8 +1297,10 @@ __global__ __launch_bounds__(1024) void k_tile_ring_scan(const TileOrderArgs a)
 __global__ __launch_bounds__(256) void k_tile_ring_scatter(const TileOrderArgs a)
 {
     const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
-    if (tile < a.n_tiles)
-        a.order[atomicAdd(&a.rings[tile_ring(a, tile)], 1u)] = tile;
+    const bool valid = tile < a.n_tiles;
+    const uint32_t place = ring_add(a.rings, valid, valid ? tile_ring(a, tile) : 0u);
+    if (valid)
+        a.order[place] = tile;
 }
 
 uint32_t grid_for_waves(uint64_t waves) { return (uint32_t)((waves + (kBlock / 64) - 1) / (kBlock / 64)); }

@@ -98,6 +98,41 @@ RT_LAYOUT_FN bool cw_is_big(uint32_t w) { return (w >> 31) != 0u; }
 RT_LAYOUT_FN uint32_t cw_big_count(uint32_t w) { return (w & 0x7fffffffu) >> 6; }
 RT_LAYOUT_FN uint32_t cw_make_big(uint32_t count) { return 0x80000000u | (count << 6); }
 
+// ---- The traversal structure of our own (rt_wide.h) ------------------------------------------------------
+// The reference's visit set does not depend on the tree ABOVE its leaves: its box test is monotone under box
+// inclusion (rt_wide.h has the argument and its three exceptions), so a leaf is visited exactly when its OWN
+// box passes the exact test. The kernels therefore walk a 4-wide SAH tree built over the TRIANGLES (not the
+// reference's median-split tree) with cheap conservative box tests, run the reference's exact triangle test
+// on the leaves' triangles, and check a would-be candidate against the exact test of the reference leaf it
+// lives in (the winner only: rt_wide.h). Tie ranks (the index in the reference's visit order) ride along per slot.
+//
+// WideNode: four children, SoA so that one child is one lane of a float4. 128 bytes, 128-byte aligned.
+// Child reference word:
+//   0xffffffff          empty slot
+//   bit 31 set          leaf group: bits 30:29 = triangles - 1 (1..4), bits 23:0 = group index;
+//                       group g holds slots [4g, 4g + count) of `wide_leaf` / `wide_index`
+//   otherwise           internal node: index into the WideNode array (< 2^26)
+struct alignas(128) WideNode {
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    uint32_t ref[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
+constexpr uint32_t kWideEmpty = 0xffffffffu;
+constexpr uint32_t kWideMaxNodes = 1u << 26, kWideMaxGroups = 1u << 24;
+RT_LAYOUT_FN bool wide_is_leaf(uint32_t ref) { return (ref >> 31) != 0u; }
+RT_LAYOUT_FN uint32_t wide_leaf_group(uint32_t ref) { return ref & 0xffffffu; }
+RT_LAYOUT_FN uint32_t wide_leaf_count(uint32_t ref) { return ((ref >> 29) & 3u) + 1u; }
+RT_LAYOUT_FN uint32_t wide_make_leaf(uint32_t group, uint32_t count) { return 0x80000000u | ((count - 1u) << 29) | group; }
+
+// Bounds of one reference leaf (what bvh.cpp:331-352 tests before the leaf is scanned), 32 bytes
+struct alignas(16) LeafBox {
+    float lo[3], hi[3];
+    uint32_t pad[2];
+};
+static_assert(sizeof(LeafBox) == 32, "LeafBox");
+
 // Material slot (framework mesh.h:22-34 without the shared_ptr)
 struct alignas(16) MaterialRec {
     float kd[3];
@@ -154,6 +189,13 @@ struct SceneView {
     const float4* diag_leaf;
 #endif
     uint32_t leaf_flush; // leaf-queue fill at which the wave switches to the leaf phase (tuning, 2..64)
+    // the wide tree (rt_wide.h); wide_ok == 0: not built for this scene (spheres, a root that is a leaf, too large)
+    const WideNode* wide_nodes;
+    const float4* wide_leaf;      // LeafRecords, four slots per group (padding slots are zero)
+    const uint32_t* wide_index;    // per slot: the triangle's position in `prims` (the reference's visit order)
+    const uint32_t* wide_ref_leaf; // per entry of `prims`: the reference leaf it lives in
+    const LeafBox* wide_leaf_box;  // per reference leaf
+    uint32_t wide_n_nodes, wide_n_groups, wide_n_ref_leaves, wide_ok;
 };
 
 } // namespace rt

@@ -19,6 +19,7 @@
 //    on the surviving groups, four lanes each (rt_layout.h GroupRecord).
 #pragma once
 #include "rt_device.h"
+#include "rt_wide.h"
 
 namespace rt {
 
@@ -465,10 +466,23 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
     const unsigned long long stamp_begin = clock64();
 #endif
 
-    if (!use_bvh || sv.root_cnt != 0u) // the root is a leaf / brute force: one ungrouped range per ray
+    if (!use_bvh || sv.root_cnt != 0u) { // the root is a leaf / brute force: one ungrouped range per ray
         w.queue_leaves(active, lane, use_bvh ? sv.root_ref : 0u, use_bvh ? sv.root_cnt : cw_make_big(sv.n_prims), 0.0f);
-    else // the root's own box is never tested (bvh.cpp:313)
+    } else if (prune && sv.wide_ok != 0u) {
+        // The wide engine (rt_wide.h) for the rays it is proven for; the exact-topology engine for the others
+        // (zero / tiny / huge / NaN components) and for those the wide engine hands back.
+        const bool fast = active && inv.all_ok();
+        const uint64_t back = traverse_wide<MODE, COUNT>(sv, fast, ray, inv, lc, L, lane);
+        const bool slow = active && (!fast || ((back >> lane) & 1ull) != 0ull);
+        if (ballot(slow)) {
+            if (slow)
+                L.best[lane] = kNoHit;
+            wave_lds_fence();
+            w.lane_engine(0u, slow, sv.root_ref, 0.0f);
+        }
+    } else { // the root's own box is never tested (bvh.cpp:313)
         w.lane_engine(0u, active, sv.root_ref, 0.0f);
+    }
     w.flush_leaves(1u);
     wave_lds_fence();
     const unsigned long long key = L.best[lane];

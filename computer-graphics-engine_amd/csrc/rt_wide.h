@@ -1,0 +1,293 @@
+// rt_wide.h — the wide engine: traversal of our own 4-wide SAH tree (rt_layout.h WideNode, host_wide.cpp)
+// that returns the bits of the reference's traversal of ITS tree.
+//
+// Why a different tree may be walked. For a ray whose three direction components are non-zero, finite and of
+// moderate magnitude and whose origin is finite (RayInv::all_ok) every slab quotient of the reference's box
+// test is finite, and the test reduces to
+//     T(box) = tin < 0 ? tout > 0 : tin <= tout        (ray.t = FLT_MAX at the call, bvh.cpp:336,344)
+// with tin = max over the axes of the nearer quotient, tout = min of the farther one. RN(x - o) and RN(n / d)
+// are monotone, so for a child box inside its parent's box every nearer quotient of the parent is <= the
+// child's and every farther one >=: tin_p <= tin_c, tout_p >= tout_c. Hence T(child) implies T(parent),
+// except when tout_p == 0 with tin_p < 0 — and then 0 <= tin_c <= tout_c <= tout_p = 0. The reference's node
+// boxes are exact unions of their primitives' bounds, every box is inside its parent's, and the root's own box
+// is never tested (bvh.cpp:313). So for such a ray
+//     the reference visits a leaf  <=>  T(leaf's own box), unless that test passes with tout == 0,
+// whatever the tree above the leaves looks like. The wide engine therefore
+//   * walks the wide tree with a CONSERVATIVE box test: one FMA per slab plane, the interval widened by the
+//     pruning slack (rt_device.h "Pruning": a candidate's point lies within rho = 2^-16 x scene scale of its
+//     triangle, hence of every box around it; the FMA form adds at most 2^-22 x scale x |1/d| of rounding,
+//     1/64 of the slack), pruned by min(initial ray.t, best t so far) like the exact engine;
+//   * runs the reference's exact triangle test (Appendix A.1/A.2) on the triangles of the leaf groups reached;
+//   * keeps, per ray, the smallest key among ALL triangles that pass that test (wide_index gives a slot's index in
+//     the reference's visit order, so ties resolve as there) and prunes with it;
+//   * at the end checks the WINNER against the exact box test of the reference leaf it lives in (wide_ref_leaf,
+//     LeafBox) — the reference's "is this leaf visited". If the winner's leaf is visited, the winner is the
+//     reference's result: every triangle of a visited leaf that passes the test was a contender (pruning only cut
+//     subtrees whose lower bound exceeded some contender's t >= the winner's), and the contenders are a superset
+//     of the reference's candidates, so the smallest key among them, being one of the reference's candidates, is
+//     the smallest of those. (A shadow ray's winner is "some blocker": valid as soon as its leaf is visited.)
+//   * sends a ray to the exact-topology engine (rt_traverse.h) when the winner's leaf fails that test or passes it
+//     with tout == 0, when the ray is not all_ok (zero / tiny / huge / NaN components), or when a lane's deque
+//     would overflow. Rare: a ray has to graze the corner of a leaf box for the first, sit on a box face for the second.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+template <int MODE>
+RT_DEV bool wide_any_hit_slot(uint32_t r)
+{
+    return MODE == 1 /* Q_ANY */ || (MODE == 2 /* Q_MIXED */ && r >= 32u);
+}
+
+RT_DEV uint32_t lb_to_u16(float lb) { return lb > 0.0f ? (__float_as_uint(lb) >> 16) : 0u; } // NaN / negative: no bound
+RT_DEV float u16_to_lb(uint32_t h) { return __uint_as_float(h << 16); }
+
+template <int MODE, bool COUNT>
+struct WideWalk {
+    const SceneView& sv;
+    WaveLds& L;
+    LaneCounters& lc;
+    uint32_t lane;
+    BufRsrc nodes, leaf, index;
+    uint32_t lq_n = 0; // wave-uniform fill of the leaf queue
+    uint32_t flush_at;
+
+    RT_DEV void flag_fallback(uint32_t r) { atomicOr(&L.wfallback[r >> 5], 1u << (r & 31u)); }
+
+    // ---- leaf phase: four lanes per (ray, leaf group) pair, one triangle per lane ------------------------
+    RT_DEV void flush_leaves()
+    {
+        wave_lds_fence();
+        for (uint32_t base = 0; base < lq_n; base += 16u) {
+            const uint32_t p = base + (lane >> 2), j = lane & 3u;
+            if (p < lq_n) {
+                const uint32_t e = L.wlq[p], r = e >> 26, g = e & 0xffffffu, cnt = ((e >> 24) & 3u) + 1u;
+                const bool any = wide_any_hit_slot<MODE>(r);
+                const float4 rb = L.rayB[r];
+                const unsigned long long bk = L.best[r];
+                const uint32_t t0b = __float_as_uint(rb.z), bb = (uint32_t)(bk >> 32);
+                const float lim = __uint_as_float((any || t0b < bb) ? t0b : bb);
+                const bool done = any & (bk != kNoHit);
+                if (j < cnt && !done) {
+                    const uint32_t slot = g * 4u + j, off = slot * 48u;
+                    const float4 c0 = buf_load16(leaf, off), c1 = buf_load16(leaf, off + 16u), c2 = buf_load16(leaf, off + 32u);
+                    const uint32_t idx = __builtin_amdgcn_raw_buffer_load_b32(index, slot * 4u, 0, 0);
+                    const float4 a = L.rayA[r];
+                    RayL ray;
+                    ray.o = mk(a.x, a.y, a.z), ray.d = mk(a.w, rb.x, rb.y);
+                    const V3 v0 = mk(c0.x, c0.y, c0.z), v1 = mk(c0.w, c1.x, c1.y);
+                    const V3 v2 = mk(c1.z, c1.w, c2.x), n = mk(c2.y, c2.z, c2.w);
+                    float tt;
+                    // `lim` lies in [best t so far, initial ray.t]: "<=" keeps equal-t ties (rt_device.h)
+                    if (tri_candidate_leaf(v0, v1, v2, n, ray, lim, tt))
+                        atomicMin(&L.best[r], make_key(tt, idx, false));
+                    if (COUNT)
+                        lc.tri++, lc.tri_fetch++;
+                }
+            }
+#ifdef RT_TIMELINE
+            lc.tl_leaf_steps++;
+#endif
+            wave_lds_fence();
+        }
+        lq_n = 0;
+    }
+
+    RT_DEV void queue_leaf(bool want, uint32_t r, uint32_t ref)
+    {
+        const uint64_t m = ballot(want);
+        if (m) {
+            if (want) // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
+                L.wlq[lq_n + prefix_count(m)] = (ref & 0xffffffu) | (((ref >> 29) & 3u) << 24) | (r << 26);
+            lq_n += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+
+    // ---- node phase: private deques + work stealing, as in the exact engine -------------------------------
+    // Lanes with `seed` start at the root with their own ray. Returns the mask of ray slots for the exact engine.
+    RT_DEV uint64_t run(bool seed)
+    {
+        if (lane < 2u)
+            L.wfallback[lane] = 0u;
+        wave_lds_fence();
+        uint32_t bot = 0, sp = 0;
+        bool have = seed;
+        uint32_t e = lane; // node 0, ray = lane
+        float e_lb = 0.0f;
+        for (;;) {
+            if (!have && sp > bot) {
+                sp--;
+                e = L.wstack[sp][lane];
+                e_lb = u16_to_lb(L.wstack_lb[sp][lane]);
+                if (sp == bot)
+                    sp = bot = 0;
+                have = true;
+            }
+            const uint64_t busy = ballot(have);
+            if (busy == 0)
+                break;
+#ifdef RT_TIMELINE
+            lc.tl_node_iters++;
+#endif
+            if (busy != ~0ull) { // idle lanes take the OLDEST deque entry (largest subtree) of a busy lane
+                const bool donor = sp > bot;
+                const uint64_t donors = ballot(donor);
+                if (donors) {
+                    const uint64_t idle = ~busy;
+                    const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+                    const uint32_t n_don = (uint32_t)__builtin_popcountll(donors);
+                    const uint32_t n_x = n_idle < n_don ? n_idle : n_don;
+                    if (donor) {
+                        const uint32_t k = prefix_count(donors);
+                        if (k < n_x) {
+                            L.xfer[k] = L.wstack[bot][lane];
+                            L.wxfer_lb[k] = L.wstack_lb[bot][lane];
+                            bot++;
+                            if (sp == bot)
+                                sp = bot = 0;
+                        }
+                    }
+                    wave_lds_fence();
+                    if (!have) {
+                        const uint32_t k = prefix_count(idle);
+                        if (k < n_x) {
+                            e = L.xfer[k];
+                            e_lb = u16_to_lb(L.wxfer_lb[k]);
+                            have = true;
+                        }
+                    }
+                    wave_lds_fence();
+                }
+            }
+            bool lf[4] = { false, false, false, false };
+            uint32_t ref[4] = { 0u, 0u, 0u, 0u };
+            uint32_t r = 0;
+            if (have) {
+                have = false;
+                r = e & 63u;
+                const bool any = wide_any_hit_slot<MODE>(r);
+                const unsigned long long bk = L.best[r];
+                const float4 ra = L.rayA[r], rb = L.rayB[r], rc = L.rayC[r];
+                const uint32_t t0b = __float_as_uint(rb.z), bb = (uint32_t)(bk >> 32);
+                const float lim = __uint_as_float((any || t0b < bb) ? t0b : bb); // shadow rays: t0; else min(t0, best t)
+                const bool skip = (any & (bk != kNoHit)) | (!any & (e_lb > lim));
+                if (!skip) {
+                    const uint32_t noff = (e >> 6) * 128u;
+                    const float4 lox = buf_load16(nodes, noff), loy = buf_load16(nodes, noff + 16u);
+                    const float4 loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
+                    const float4 hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
+                    const float4 rf = buf_load16(nodes, noff + 96u);
+                    ref[0] = __float_as_uint(rf.x), ref[1] = __float_as_uint(rf.y);
+                    ref[2] = __float_as_uint(rf.z), ref[3] = __float_as_uint(rf.w);
+                    // t = b * (1/d) - o * (1/d): one FMA per slab plane; s covers its rounding and the box growth rho
+                    const float s = rc.w * 1.0625f;
+                    const float ox = ra.x * rc.x, oy = ra.y * rc.y, oz = ra.z * rc.z;
+                    const float s2 = s + s, ms = -s, lims = lim + s;
+                    const float bx0[4] = { lox.x, lox.y, lox.z, lox.w }, bx1[4] = { hix.x, hix.y, hix.z, hix.w };
+                    const float by0[4] = { loy.x, loy.y, loy.z, loy.w }, by1[4] = { hiy.x, hiy.y, hiy.z, hiy.w };
+                    const float bz0[4] = { loz.x, loz.y, loz.z, loz.w }, bz1[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+                    bool in[4];
+                    float lbk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float tx0 = __builtin_fmaf(bx0[k], rc.x, -ox), tx1 = __builtin_fmaf(bx1[k], rc.x, -ox);
+                        const float ty0 = __builtin_fmaf(by0[k], rc.y, -oy), ty1 = __builtin_fmaf(by1[k], rc.y, -oy);
+                        const float tz0 = __builtin_fmaf(bz0[k], rc.z, -oz), tz1 = __builtin_fmaf(bz1[k], rc.z, -oz);
+                        const float tin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+                        const float tout = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+                        // may the ray pass within the slack of the box at a distance in [0, lim]? (positive comparisons:
+                        // a NaN — impossible for an all_ok ray and a finite box — would drop the child, never a real one)
+                        const bool hit = (tin <= tout + s2) & (tout >= ms) & (tin <= lims) & (ref[k] != kWideEmpty);
+                        lbk[k] = tin - s;
+                        lf[k] = hit & wide_is_leaf(ref[k]);
+                        in[k] = hit & !wide_is_leaf(ref[k]);
+                    }
+                    if (COUNT) {
+                        lc.node_fetch++;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            lc.box += ref[k] != kWideEmpty ? 1u : 0u;
+                    }
+                    // the nearest internal child becomes the current entry, the others are put aside
+                    int near = -1;
+                    float near_lb = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool better = in[k] & ((near < 0) | (lbk[k] < near_lb));
+                        near = better ? k : near;
+                        near_lb = better ? lbk[k] : near_lb;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (in[k] & (k != near)) {
+                            if (sp < kWideStack) {
+                                L.wstack[sp][lane] = (ref[k] << 6) | r;
+                                L.wstack_lb[sp][lane] = (uint16_t)lb_to_u16(lbk[k]);
+                                sp++;
+                            } else {
+                                flag_fallback(r); // no room: the exact engine traces this ray
+                            }
+                        }
+                    }
+                    if (near >= 0) {
+                        const uint32_t nref = near == 0 ? ref[0] : (near == 1 ? ref[1] : (near == 2 ? ref[2] : ref[3]));
+                        e = (nref << 6) | r;
+                        e_lb = near_lb;
+                        have = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                queue_leaf(lf[k], r, ref[k]);
+            if (lq_n >= flush_at)
+                flush_leaves();
+        }
+        if (lq_n)
+            flush_leaves();
+        wave_lds_fence();
+        return (uint64_t)L.wfallback[0] | ((uint64_t)L.wfallback[1] << 32);
+    }
+};
+
+// The winner of ray slot `lane` (L.best) against the reference's own test of the leaf it lives in: true when the
+// reference visits that leaf for certain (exact A.4 on the leaf's box passes with tout != 0), i.e. the winner stands.
+template <bool COUNT>
+RT_DEV bool wide_winner_stands(const SceneView& sv, const RayL& ray, const RayInv& inv, unsigned long long key, LaneCounters& lc)
+{
+    const uint32_t ref_leaf = sv.wide_ref_leaf[key_index(key)];
+    const float4* bp = reinterpret_cast<const float4*>(sv.wide_leaf_box + ref_leaf);
+    const float4 b0 = bp[0], b1 = bp[1];
+    const float lo[3] = { b0.x, b0.y, b0.z }, hi[3] = { b0.w, b1.x, b1.y };
+    float tl[3], th[3];
+    slab_quotients(lo, hi, ray, inv, tl, th); // the reference's six quotients, bit for bit
+    // A.4 with every quotient finite (all_ok ray, finite box): tin < 0 ? tout > 0 : tin <= tout
+    const float tin = sel_max(sel_min(th[2], tl[2]), sel_max(sel_min(th[1], tl[1]), sel_min(th[0], tl[0])));
+    const float tout = sel_min(sel_max(th[2], tl[2]), sel_min(sel_max(th[1], tl[1]), sel_max(th[0], tl[0])));
+    if (COUNT)
+        lc.box++;
+    return (tin < 0.0f ? tout > 0.0f : tin <= tout) && tout != 0.0f;
+}
+
+// Ray slots with `fast` set (all_ok rays: the caller checks) are traced through the wide tree (closest hit /
+// any hit per slot as MODE says); on return L.best holds their keys, and the returned mask names the slots whose
+// result must be discarded and traced by the exact engine instead. `ray` / `inv`: the lane's own ray (slot = lane).
+// ALL lanes of the wave must call.
+template <int MODE, bool COUNT>
+RT_DEV uint64_t traverse_wide(const SceneView& sv, bool fast, const RayL& ray, const RayInv& inv, LaneCounters& lc,
+    WaveLds& L, uint32_t lane)
+{
+    uint32_t flush_at = sv.leaf_flush < kWideFlushMax ? sv.leaf_flush : kWideFlushMax;
+    WideWalk<MODE, COUNT> w { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 128u),
+        make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u), 0u,
+        flush_at < 1u ? 1u : flush_at };
+    uint64_t back = w.run(fast);
+    const unsigned long long key = L.best[lane];
+    bool redo = false;
+    if (fast && key != kNoHit)
+        redo = !wide_winner_stands<COUNT>(sv, ray, inv, key, lc);
+    return back | ballot(redo);
+}
+
+} // namespace rt

@@ -1,0 +1,306 @@
+// tools/wide_sim.cpp — CPU statistics of the wide-tree traversal policy (diagnostic, not part of the library or
+// the tests): node steps, child-box tests, leaf-group visits and triangle tests per primary / shadow-like ray of
+// a dumped scene, for the tree host_wide.cpp builds, next to the reference-topology tree's pair steps.
+//   python tools/wide_sim.py   (dumps the bench scene, builds and runs this)
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../computer-graphics-engine_amd/csrc/host_scene.h"
+
+using namespace rt;
+
+struct D3 {
+    double x, y, z;
+};
+static D3 sub(D3 a, D3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+static D3 cross(D3 a, D3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+static double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+struct Ray {
+    D3 o, d, inv;
+};
+
+static bool slab(const float lo[3], const float hi[3], const Ray& r, double lim, double& tin)
+{
+    const double o[3] = { r.o.x, r.o.y, r.o.z }, inv[3] = { r.inv.x, r.inv.y, r.inv.z };
+    double t0 = -1e300, t1 = 1e300;
+    for (int a = 0; a < 3; a++) {
+        double l = (lo[a] - o[a]) * inv[a], h = (hi[a] - o[a]) * inv[a];
+        if (l > h)
+            std::swap(l, h);
+        t0 = std::max(t0, l), t1 = std::min(t1, h);
+    }
+    tin = t0;
+    return t0 <= t1 && t1 >= 0 && t0 <= lim;
+}
+
+static bool tri_hit(const PrimRecord& p, const Ray& r, double& t)
+{
+    const D3 v0 { p.v0[0], p.v0[1], p.v0[2] }, v1 { p.v1[0], p.v1[1], p.v1[2] }, v2 { p.v2[0], p.v2[1], p.v2[2] };
+    const D3 e1 = sub(v1, v0), e2 = sub(v2, v0), pv = cross(r.d, e2);
+    const double det = dot(e1, pv);
+    if (std::fabs(det) < 1e-300)
+        return false;
+    const D3 tv = sub(r.o, v0);
+    const double u = dot(tv, pv) / det;
+    if (u < 0 || u > 1)
+        return false;
+    const D3 qv = cross(tv, e1);
+    const double v = dot(r.d, qv) / det;
+    if (v < 0 || u + v > 1)
+        return false;
+    t = dot(e2, qv) / det;
+    return t >= 0;
+}
+
+struct Stats {
+    double rays = 0, steps = 0, child_tests = 0, leaf_visits = 0, tri_tests = 0, stale_pops = 0, max_stack = 0, hits = 0;
+};
+
+// order: 0 = children pushed in slot order, nearest current; 1 = fully sorted
+static void trace_wide(const HostBvh& b, const Ray& r, bool any_hit, double tmax, int order, Stats& st, double& t_out)
+{
+    struct E {
+        uint32_t node;
+        double lb;
+    };
+    std::vector<E> stack;
+    double best = tmax;
+    bool found = false;
+    E cur { 0, 0 };
+    bool have = true;
+    st.rays++;
+    for (;;) {
+        if (!have) {
+            if (stack.empty())
+                break;
+            cur = stack.back();
+            stack.pop_back();
+            have = true;
+            if (cur.lb > best) {
+                st.stale_pops++;
+                have = false;
+                continue;
+            }
+        }
+        have = false;
+        st.steps++;
+        const WideNode& n = b.wide_nodes[cur.node];
+        E kids[4];
+        int nk = 0;
+        for (int k = 0; k < 4; k++) {
+            if (n.ref[k] == kWideEmpty)
+                continue;
+            st.child_tests++;
+            const float lo[3] = { n.lox[k], n.loy[k], n.loz[k] }, hi[3] = { n.hix[k], n.hiy[k], n.hiz[k] };
+            double tin;
+            if (!slab(lo, hi, r, best, tin))
+                continue;
+            if (wide_is_leaf(n.ref[k])) {
+                st.leaf_visits++;
+                const uint32_t g = wide_leaf_group(n.ref[k]), c = wide_leaf_count(n.ref[k]);
+                for (uint32_t j = 0; j < c; j++) {
+                    st.tri_tests++;
+                    double t;
+                    if (tri_hit(b.records[b.wide_slot_src[4 * g + j]], r, t) && t <= best)
+                        best = t, found = true;
+                }
+            } else {
+                kids[nk++] = E { n.ref[k], tin };
+            }
+        }
+        if (any_hit && found)
+            break;
+        if (nk) {
+            int near = 0;
+            for (int k = 1; k < nk; k++)
+                if (kids[k].lb < kids[near].lb)
+                    near = k;
+            std::swap(kids[near], kids[nk - 1]);
+            if (order == 1)
+                std::sort(kids, kids + nk - 1, [](const E& a, const E& c) { return a.lb > c.lb; });
+            for (int k = 0; k < nk - 1; k++)
+                stack.push_back(kids[k]);
+            cur = kids[nk - 1];
+            have = true;
+            st.max_stack = std::max(st.max_stack, (double)stack.size());
+        }
+    }
+    if (found)
+        st.hits++;
+    t_out = found ? best : -1;
+}
+
+// the exact-topology tree with today's policy (pair steps, near child first, pruning)
+static void trace_pairs(const HostBvh& b, const Ray& r, bool any_hit, double tmax, Stats& st)
+{
+    struct E {
+        uint32_t node;
+        double lb;
+    };
+    std::vector<E> stack { { b.root_ref, 0 } };
+    double best = tmax;
+    bool found = false;
+    st.rays++;
+    while (!stack.empty()) {
+        const E e = stack.back();
+        stack.pop_back();
+        if (e.lb > best) {
+            st.stale_pops++;
+            continue;
+        }
+        st.steps++;
+        const NodePair& p = b.pairs[e.node];
+        E kids[2];
+        int nk = 0;
+        for (int k = 0; k < 2; k++) {
+            const float* lo = k ? p.r_lo : p.l_lo;
+            const float* hi = k ? p.r_hi : p.l_hi;
+            const uint32_t ref = k ? p.r_ref : p.l_ref, cw = k ? p.r_cnt : p.l_cnt;
+            st.child_tests++;
+            double tin;
+            if (!slab(lo, hi, r, best, tin))
+                continue;
+            if (cw != 0) {
+                st.leaf_visits++;
+                const uint32_t cnt = cw_is_big(cw) ? cw_big_count(cw) : (cw & 63u);
+                // culling groups: count the group tests as child tests, the triangles of groups the ray may touch
+                if (!cw_is_big(cw)) {
+                    const uint32_t g0 = cw >> 6;
+                    for (uint32_t g = 0; g * 4 < cnt; g++) {
+                        st.child_tests++;
+                        const GroupRecord& gr = b.groups[g0 + g];
+                        double gt;
+                        if (!slab(gr.lo, gr.hi, r, best, gt))
+                            continue;
+                        for (uint32_t j = 0; j < 4; j++) {
+                            const uint32_t src = b.grouped_src[(g0 + g) * 4 + j];
+                            if (src == 0xffffffffu)
+                                continue;
+                            st.tri_tests++;
+                            double t;
+                            if (tri_hit(b.records[src], r, t) && t <= best)
+                                best = t, found = true;
+                        }
+                    }
+                } else {
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        st.tri_tests++;
+                        double t;
+                        if (tri_hit(b.records[ref + j], r, t) && t <= best)
+                            best = t, found = true;
+                    }
+                }
+            } else {
+                kids[nk++] = E { ref, tin };
+            }
+        }
+        if (any_hit && found)
+            break;
+        if (nk == 2 && kids[0].lb < kids[1].lb)
+            std::swap(kids[0], kids[1]);
+        for (int k = 0; k < nk; k++)
+            stack.push_back(kids[k]);
+        st.max_stack = std::max(st.max_stack, (double)stack.size());
+    }
+}
+
+static void report(const char* name, const Stats& s)
+{
+    printf("%-34s rays %8.0f  steps/ray %6.2f  box tests/ray %6.2f  leaf visits/ray %5.2f  tri tests/ray %5.2f  stale pops/ray %5.2f  max stack %3.0f  hits %.0f\n",
+        name, s.rays, s.steps / s.rays, s.child_tests / s.rays, s.leaf_visits / s.rays, s.tri_tests / s.rays,
+        s.stale_pops / s.rays, s.max_stack, s.hits);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) {
+        fprintf(stderr, "usage: wide_sim scene.bin [stride]\n");
+        return 2;
+    }
+    const int stride = argc > 2 ? atoi(argv[2]) : 4;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f)
+        return 1;
+    uint32_t nv, nt;
+    float cam[9]; // origin[3], quat[4], half_w, half_h
+    int32_t wh[2];
+    if (fread(&nv, 4, 1, f) != 1 || fread(&nt, 4, 1, f) != 1 || fread(cam, 4, 9, f) != 9 || fread(wh, 4, 2, f) != 2)
+        return 1;
+    std::vector<float> pos(3 * (size_t)nv);
+    std::vector<uint32_t> tri(3 * (size_t)nt);
+    if (fread(pos.data(), 4, pos.size(), f) != pos.size() || fread(tri.data(), 4, tri.size(), f) != tri.size())
+        return 1;
+    fclose(f);
+    rt_mesh_desc md;
+    memset(&md, 0, sizeof(md));
+    md.positions = pos.data(), md.triangles = tri.data(), md.n_vertices = nv, md.n_triangles = nt;
+    md.material.texture = -1;
+    rt_scene_desc sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.meshes = &md, sd.n_meshes = 1;
+    HostScene hs;
+    const std::string err = hs.load(sd);
+    if (!err.empty()) {
+        fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    HostBvh hb;
+    const std::string e2 = hb.build(hs, false);
+    if (!e2.empty() || !hb.wide_ok) {
+        fprintf(stderr, "build: %s wide_ok %d\n", e2.c_str(), (int)hb.wide_ok);
+        return 1;
+    }
+    size_t groups = hb.wide_slot_src.size() / 4, used = 0;
+    for (uint32_t s : hb.wide_slot_src)
+        used += s != 0xffffffffu;
+    printf("triangles %u: reference tree %zu pairs / %d leaves; wide tree %zu nodes, %zu groups (%.2f triangles each), depth %u\n",
+        nt, hb.pairs.size(), hb.num_leaves, hb.wide_nodes.size(), groups, (double)used / groups, hb.wide_depth);
+
+    const int W = wh[0], H = wh[1];
+    auto qrot = [&](D3 v) {
+        const D3 q { cam[4], cam[5], cam[6] };
+        const double w = cam[3];
+        const D3 uv = cross(q, v), uuv = cross(q, uv);
+        return D3 { v.x + (uv.x * w + uuv.x) * 2, v.y + (uv.y * w + uuv.y) * 2, v.z + (uv.z * w + uuv.z) * 2 };
+    };
+    Stats wide0, wide1, pairs, sh_wide, sh_pairs;
+    const D3 light { -1, 1, -1 };
+    for (int y = 0; y < H; y += stride)
+        for (int x = 0; x < W; x += stride) {
+            const double px = (double)x / W * 2 - 1, py = (double)y / H * 2 - 1;
+            D3 c { -px * cam[7], py * cam[8], 1 };
+            const double l = std::sqrt(dot(c, c));
+            c = { c.x / l, c.y / l, c.z / l };
+            Ray r;
+            r.o = { cam[0], cam[1], cam[2] };
+            r.d = qrot(c);
+            r.inv = { 1 / r.d.x, 1 / r.d.y, 1 / r.d.z };
+            double tin;
+            if (!slab(hb.nodes.back().lo, hb.nodes.back().hi, r, 1e300, tin))
+                continue; // rays that miss the scene bounds never reach the traversal
+            double t;
+            trace_wide(hb, r, false, 1e300, 0, wide0, t);
+            trace_wide(hb, r, false, 1e300, 1, wide1, t);
+            trace_pairs(hb, r, false, 1e300, pairs);
+            if (t > 0) { // its shadow ray
+                Ray s;
+                const D3 p { r.o.x + r.d.x * (t - 1e-5), r.o.y + r.d.y * (t - 1e-5), r.o.z + r.d.z * (t - 1e-5) };
+                s.o = p, s.d = sub(light, p);
+                s.inv = { 1 / s.d.x, 1 / s.d.y, 1 / s.d.z };
+                double ts;
+                trace_wide(hb, s, true, 1.0, 0, sh_wide, ts);
+                trace_pairs(hb, s, true, 1.0, sh_pairs);
+            }
+        }
+    report("closest, wide tree, nearest first", wide0);
+    report("closest, wide tree, sorted pushes", wide1);
+    report("closest, reference tree + groups", pairs);
+    report("shadow, wide tree", sh_wide);
+    report("shadow, reference tree + groups", sh_pairs);
+    return 0;
+}
