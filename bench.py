@@ -257,8 +257,8 @@ def main():
     # ---- one frame at a time (N = 1): the library's latency setting, no launches in flight ------------------
     frame_ms_serial = None
     if world == 1 and not args.exchange_always:
-        rt.set_option("tile_wlog", 1)
-        rt.set_option("tile_hlog", 3)
+        rt.set_option("tile_wlog", 2)   # the library's default (latency) setting
+        rt.set_option("tile_hlog", 2)
         rt.set_option("leaf_flush", 16)
         lone = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, 0, 1, strip_rows=STRIP_ROWS, frames_in_flight=1)
         lone.prepare(stream, (1,))
@@ -273,7 +273,7 @@ def main():
             ts.append(time.perf_counter() - t0)
         frame_ms_serial = {"mean": round(float(np.mean(ts)) * 1e3, 4), "min": round(min(ts) * 1e3, 4),
                            "max": round(max(ts) * 1e3, 4), "frames": n_serial,
-                           "setting": "one frame per launch, one launch at a time, host-synchronised, 2x8-pixel tiles"}
+                           "setting": "one frame per launch, one launch at a time, host-synchronised, 4x4-pixel tiles (the library default)"}
 
     if rank == 0:
         ab = algorithmic_bytes(total, f, W * H * args.steps)
@@ -300,8 +300,8 @@ def main():
             if pj.exists() and world == 1:
                 pm = json.load(open(pj))
                 if pm.get("frames_per_launch") == main_size and pm.get("tile_log") == [
-                        int(args.tile_log[0]) if args.tile_log else (3 if fpl > 1 else (2 if renderer.flight > 1 else 1)),
-                        int(args.tile_log[1]) if args.tile_log else 3]:
+                        int(args.tile_log[0]) if args.tile_log else (3 if fpl > 1 else 2),
+                        int(args.tile_log[1]) if args.tile_log else (3 if fpl > 1 or renderer.flight > 1 else 2)]:
                     roofline["traffic"] = pm.get("hbm_bytes_per_launch")
                     v = pm.get("valu_insts_per_launch")
                     if v:

@@ -31,8 +31,11 @@ std::atomic<int> g_unpruned { 0 };
 std::atomic<int> g_leaf_flush { 16 };
 // rt_set_option("wide", 0): traverse the reference-topology tree only (the wide tree stays built)
 std::atomic<int> g_wide { 1 };
+// rt_set_option("xcd_order", 1): the tile dispatch order deals screen blocks to the XCDs (rt_kernels.h CameraArgs)
+// rt_set_option("prefetch", 1): the wide engine touches the next node's line at the end of a step
+std::atomic<int> g_xcd_order { 1 }, g_prefetch { 0 }, g_xcd_block { 4 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
-std::atomic<int> g_tile_wlog { 1 }, g_tile_hlog { 3 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
+std::atomic<int> g_tile_wlog { 2 }, g_tile_hlog { 2 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
 int fail(int code, const std::string& msg)
@@ -93,6 +96,7 @@ struct Scratch {
     std::vector<rt::CameraPose> poses; // rt_render_device_frames: the frames' poses of the launch being enqueued
     DevBuf<uint32_t> order; // tile dispatch order (tile_order_for)
     DevBuf<uint32_t> order_rings; // its ring counters
+    uint32_t xcd_count[8] = {};   // XCD-aware order: lengths of the eight lists of the cached order
     DevBuf<float> samples;   // per-sample colours of multi-sample frames (k_resolve input)
     DevBuf<float> frames;    // k_trace_general: per-wave-slot recursion frames
     DevBuf<float> bloom_src; // the frame before the bloom filter
@@ -198,6 +202,7 @@ struct rt_bvh {
         v.wide_n_groups = (uint32_t)(host.wide_slot_src.size() / 4);
         v.wide_n_ref_leaves = (uint32_t)host.wide_leaf_box.size();
         v.wide_ok = host.wide_ok && g_wide.load() ? 1u : 0u;
+        v.wide_prefetch = g_prefetch.load() ? 1u : 0u;
         v.stamps = g_stamps;
 #ifdef RT_DIAG
         v.diag_nodes = diag_nodes.p;
@@ -381,7 +386,11 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
     const int64_t period = cam.n_frames > 1 ? frame_rows / th : gh + (int64_t)cam.tile_y0;
     const int64_t lrow_mid = cam.rows ? frame_rows / 2 : std::min<int64_t>(std::max<int64_t>(cam.height / 2 - cam.row0, 0), cam.n_rows - 1);
     const int64_t cx = (cam.vwidth / 2) / tw - (int64_t)cam.tile_x0, cy = lrow_mid / th - (int64_t)cam.tile_y0;
-    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period };
+    const int64_t xcd = g_xcd_order.load() ? 1 : 0;
+    // screen blocks of 2^xcd_block pixels a side, in tiles
+    const uint32_t bpl = (uint32_t)g_xcd_block.load();
+    const uint32_t bxlog = bpl > cam.tile_wlog ? bpl - cam.tile_wlog : 0u, bylog = bpl > cam.tile_hlog ? bpl - cam.tile_hlog : 0u;
+    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period, xcd, (int64_t)cam.tile_x0, (int64_t)cam.tile_y0, (int64_t)bxlog, (int64_t)bylog };
     if (key != sc.order_key || !sc.order.p) {
         // built on the device (k_tile_ring_*): the launched grid follows the camera, and a host-built order
         // would put an upload + synchronisation into every launch of a moving camera
@@ -391,17 +400,44 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
         const int64_t step = std::min(tw, th);
         rt::TileOrderArgs o;
         o.gw = (uint32_t)gw, o.n_tiles = (uint32_t)n;
+        o.xcd_order = (uint32_t)xcd, o.xcd_bxlog = bxlog, o.xcd_bylog = bylog, o.tile_x0 = cam.tile_x0, o.tile_y0 = cam.tile_y0;
         o.tw = tw, o.th = th, o.cx = cx, o.cy = cy, o.period = period, o.step = step;
         o.n_rings = (uint32_t)(rmax / step + 2);
+        o.n_frames = (uint32_t)std::max<int64_t>(1, (gh + period - 1) / period);
         // sized for the whole tile grid once: a reallocation frees memory, which waits for the device
         HIP_TRY(sc.order.reserve((size_t)(((cam.vwidth + tw - 1) / tw) * ((cam.n_rows + th - 1) / th))));
-        HIP_TRY(sc.order_rings.reserve((size_t)cam.vwidth + (size_t)cam.n_rows + 4u));
-        if (n > sc.order.n || o.n_rings > sc.order_rings.n)
+        HIP_TRY(sc.order_rings.reserve(8u * (size_t)rt::kMaxFramesPerLaunch * ((size_t)cam.vwidth + (size_t)cam.n_rows + 4u)));
+        if (n > sc.order.n || 8u * (size_t)o.n_frames * (size_t)o.n_rings > sc.order_rings.n)
             return fail(RT_ERR_INVALID, "internal error: tile order scratch too small");
         o.rings = sc.order_rings.p, o.order = sc.order.p;
         rt::launch_tile_order(o, stream);
         HIP_TRY(hipGetLastError());
+        // XCD-aware order: the lengths of the eight lists (tile_xcd over the launched grid, row by row in runs of
+        // one screen block)
+        memset(sc.xcd_count, 0, sizeof(sc.xcd_count));
+        if (xcd) {
+            const int64_t B = (int64_t)1 << bxlog;
+            for (int64_t ty = 0; ty < gh; ty++) {
+                const uint32_t aty = (uint32_t)(ty % period) + cam.tile_y0;
+                for (int64_t tx = 0; tx < gw;) {
+                    const int64_t atx = tx + (int64_t)cam.tile_x0;
+                    const int64_t run = std::min<int64_t>(B - (atx & (B - 1)), gw - tx);
+                    sc.xcd_count[rt::tile_xcd((uint32_t)atx, aty, bxlog, bylog)] += (uint32_t)run;
+                    tx += run;
+                }
+            }
+        }
         sc.order_key = key;
+    }
+    cam.xcd_order = (uint32_t)xcd;
+    if (xcd) {
+        uint32_t base = 0, longest = 0;
+        for (int k = 0; k < 8; k++) {
+            cam.xcd_base[k] = base, cam.xcd_count[k] = sc.xcd_count[k];
+            base += sc.xcd_count[k];
+            longest = std::max(longest, sc.xcd_count[k]);
+        }
+        cam.launch_waves = 8u * longest;
     }
     cam.order = sc.order.p;
     return RT_OK;
@@ -675,6 +711,20 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "wide") == 0) {
         g_wide.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "xcd_order") == 0) {
+        g_xcd_order.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "xcd_block") == 0) { // screen blocks of 2^v x 2^v pixels go to one XCD
+        if (value < 0 || value > 10)
+            return fail(RT_ERR_INVALID, "rt_set_option: xcd_block must be in [0, 10]");
+        g_xcd_block.store(value);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "prefetch") == 0) {
+        g_prefetch.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "leaf_flush") == 0) {

@@ -28,6 +28,11 @@ struct CameraArgs {
     uint32_t tile_wlog, tile_hlog; // primary tile = 2^wlog x 2^hlog pixels per wave (<= 64)
     uint32_t super_log;            // > 0: super-tiles of 2^s x 2^s tiles dealt to the XCDs (tile_pixel)
     const uint32_t* order;         // NULL, or launch position -> tile index (heavy-first dispatch order)
+    // XCD-aware order (xcd_order != 0): workgroup b runs on XCD b % 8, and `order` holds eight lists — list x = the
+    // tiles of the screen blocks dealt to XCD x (tile_xcd), centre first — so that every XCD's L2 serves the part of
+    // the scene behind its own blocks; launch position b = the (b / 8)-th tile of list b % 8
+    uint32_t xcd_order, launch_waves; // launch_waves: 8 x the longest list
+    uint32_t xcd_base[8], xcd_count[8];
     // launched sub-grid of tiles (host_launch_rect): tiles [tile_x0, tile_x0 + tiles_w) x [tile_y0, tile_y0 + tiles_h);
     // tiles_w == 0 means the whole grid
     uint32_t tile_x0, tile_y0, tiles_w, tiles_h;
@@ -136,8 +141,16 @@ struct IntersectArgs {
 };
 
 // Dispatch order of the launched tile grid (k_tile_ring_*): rings around (cx, cy), measured in pixels
+// XCD of the tile at (tx, ty) of the tile grid (ty within its frame): screen blocks of 2^bxlog x 2^bylog tiles go
+// to one XCD; shared by host (list lengths) and device
+inline __host__ __device__ uint32_t tile_xcd(uint32_t tx, uint32_t ty, uint32_t bxlog, uint32_t bylog)
+{
+    return ((tx >> bxlog) + 3u * (ty >> bylog)) & 7u;
+}
 struct TileOrderArgs {
     uint32_t gw, n_tiles; // launched grid width in tiles, tiles in it
+    uint32_t xcd_order, xcd_bxlog, xcd_bylog, tile_x0, tile_y0; // xcd_order: sort key = (XCD of the tile, frame, ring)
+    uint32_t n_frames;                                         // frames in the launch (tile rows / period)
     int64_t tw, th, cx, cy, period, step;
     uint32_t n_rings;
     uint32_t* rings; // n_rings counters (scratch)

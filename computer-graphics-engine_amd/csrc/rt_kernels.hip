@@ -113,8 +113,18 @@ RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_
     const uint32_t tiles_x = ((uint32_t)c.vwidth + tw - 1u) >> c.tile_wlog;
     uint32_t tx, ty;
     if (c.super_log == 0) {
-        if (c.order)
-            wave = c.order[wave];
+        if (c.order) {
+            if (c.xcd_order) { // launch position -> the (wave / 8)-th tile of XCD (wave % 8)'s list
+                const uint32_t xl = wave & 7u, k = wave >> 3;
+                if (k >= c.xcd_count[xl]) {
+                    x = y = lrow = 0;
+                    return false;
+                }
+                wave = c.order[c.xcd_base[xl] + k];
+            } else {
+                wave = c.order[wave];
+            }
+        }
         if (c.tiles_w) { // launched sub-grid
             ty = wave / c.tiles_w, tx = wave - ty * c.tiles_w;
             tx += c.tile_x0, ty += c.tile_y0;
@@ -480,6 +490,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
         const uint32_t tw = 1u << a.cam.tile_wlog, th = 1u << a.cam.tile_hlog;
         n_units = a.cam.tiles_w ? a.cam.tiles_w * a.cam.tiles_h
                                 : (((uint32_t)a.cam.vwidth + tw - 1u) >> a.cam.tile_wlog) * (((uint32_t)a.cam.n_rows + th - 1u) >> a.cam.tile_hlog);
+        if (a.cam.order && a.cam.xcd_order)
+            n_units = a.cam.launch_waves; // eight lists of tiles, padded to the longest (tile_pixel)
     } else {
         n_units = (a.in_count_imm + 63u) / 64u;
     }
@@ -1242,8 +1254,13 @@ RT_DEV uint32_t tile_ring(const TileOrderArgs& a, uint32_t tile)
     const int64_t ty = tile / a.gw, tx = tile - (uint32_t)ty * a.gw;
     const int64_t dx = tx - a.cx, dy = ty % a.period - a.cy;
     const int64_t r = max((dx < 0 ? -dx : dx) * a.tw, (dy < 0 ? -dy : dy) * a.th);
-    const int64_t q = (r + a.step - 1) / a.step;
-    return (uint32_t)(q < (int64_t)a.n_rings - 1 ? q : (int64_t)a.n_rings - 1);
+    int64_t q = (r + a.step - 1) / a.step;
+    q = q < (int64_t)a.n_rings - 1 ? q : (int64_t)a.n_rings - 1;
+    if (a.xcd_order) // eight lists, one per XCD; in a list frame after frame (a frame's share of the scene fits the
+                     // XCD's L2, eight frames' shares do not), each frame centre first
+        q += ((int64_t)tile_xcd((uint32_t)tx + a.tile_x0, (uint32_t)(ty % a.period) + a.tile_y0, a.xcd_bxlog, a.xcd_bylog)
+                     * a.n_frames + ty / a.period) * a.n_rings;
+    return (uint32_t)q;
 }
 // One atomic per (wave, ring) instead of one per tile: the 64 consecutive tiles of a wave lie in a handful of
 // rings, and hundreds of thousands of single adds to a few hundred counters serialise in their L2 channels
@@ -1275,9 +1292,10 @@ __global__ __launch_bounds__(256) void k_tile_ring_count(const TileOrderArgs a)
 __global__ __launch_bounds__(1024) void k_tile_ring_scan(const TileOrderArgs a)
 {
     __shared__ uint32_t part[1024];
-    const uint32_t per = (a.n_rings + 1023u) / 1024u, b = threadIdx.x * per;
+    const uint32_t n_keys = a.n_rings * (a.xcd_order ? 8u * a.n_frames : 1u);
+    const uint32_t per = (n_keys + 1023u) / 1024u, b = threadIdx.x * per;
     uint32_t sum = 0;
-    for (uint32_t i = b; i < b + per && i < a.n_rings; i++)
+    for (uint32_t i = b; i < b + per && i < n_keys; i++)
         sum += a.rings[i];
     part[threadIdx.x] = sum;
     __syncthreads();
@@ -1288,7 +1306,7 @@ __global__ __launch_bounds__(1024) void k_tile_ring_scan(const TileOrderArgs a)
         __syncthreads();
     }
     uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t i = b; i < b + per && i < a.n_rings; i++) {
+    for (uint32_t i = b; i < b + per && i < n_keys; i++) {
         const uint32_t c = a.rings[i];
         a.rings[i] = run;
         run += c;
@@ -1310,7 +1328,7 @@ uint64_t camera_waves(const CameraArgs& c)
     const uint32_t tw = 1u << c.tile_wlog, th = 1u << c.tile_hlog;
     const uint64_t tiles_x = (c.vwidth + tw - 1) / tw, tiles_y = (c.n_rows + th - 1) / th;
     if (c.super_log == 0)
-        return c.tiles_w ? (uint64_t)c.tiles_w * c.tiles_h : tiles_x * tiles_y;
+        return c.order && c.xcd_order ? (uint64_t)c.launch_waves : (c.tiles_w ? (uint64_t)c.tiles_w * c.tiles_h : tiles_x * tiles_y);
     const uint32_t s = c.super_log;
     const uint64_t chunks = ((tiles_x + (1u << s) - 1) >> s) * ((tiles_y + (1u << s) - 1) >> s);
     return ((chunks + 7) / 8 * 8) << (2 * s); // whole super-tiles, a multiple of 8 of them (tile_pixel)
@@ -1383,7 +1401,7 @@ void launch_tile_order(const TileOrderArgs& a, hipStream_t s)
 {
     if (a.n_tiles == 0)
         return;
-    (void)hipMemsetAsync(a.rings, 0, (size_t)a.n_rings * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(a.rings, 0, (size_t)a.n_rings * (a.xcd_order ? 8u * a.n_frames : 1u) * sizeof(uint32_t), s);
     const uint32_t grid = (a.n_tiles + 255u) / 256u;
     hipLaunchKernelGGL(k_tile_ring_count, dim3(grid), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_tile_ring_scan, dim3(1), dim3(1024), 0, s, a);

@@ -196,6 +196,7 @@ struct SceneView {
     const uint32_t* wide_ref_leaf; // per entry of `prims`: the reference leaf it lives in
     const LeafBox* wide_leaf_box;  // per reference leaf
     uint32_t wide_n_nodes, wide_n_groups, wide_n_ref_leaves, wide_ok;
+    uint32_t wide_prefetch; // tuning: touch the next node's line at the end of a node step
 };
 
 } // namespace rt

@@ -115,6 +115,8 @@ struct WideWalk {
         bool have = seed;
         uint32_t e = lane; // node 0, ray = lane
         float e_lb = 0.0f;
+        uint32_t touched = 0u; // the dword the previous step requested from this step's node (prefetch)
+        const bool prefetch = sv.wide_prefetch != 0u;
         for (;;) {
             if (!have && sp > bot) {
                 sp--;
@@ -178,6 +180,7 @@ struct WideWalk {
                     const float4 loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
                     const float4 hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
                     const float4 rf = buf_load16(nodes, noff + 96u);
+                    asm volatile("" ::"v"(touched)); // the touch is over by now (loads return in order)
                     ref[0] = __float_as_uint(rf.x), ref[1] = __float_as_uint(rf.y);
                     ref[2] = __float_as_uint(rf.z), ref[3] = __float_as_uint(rf.w);
                     // t = b * (1/d) - o * (1/d): one FMA per slab plane; s covers its rounding and the box growth rho
@@ -235,6 +238,8 @@ struct WideWalk {
                         e = (nref << 6) | r;
                         e_lb = near_lb;
                         have = true;
+                        if (prefetch) // bring the next node's line towards this CU while the step's bookkeeping runs
+                            touched = __builtin_amdgcn_raw_buffer_load_b32(nodes, nref * 128u, 0, 0);
                     }
                 }
             }

@@ -1,21 +1,23 @@
 """The library's tuning options (rt_set_option) only change HOW the frame is computed: every setting
 gives the bits of the default one — tile shapes (the bench's throughput setting is 8x8), per-level launches
 instead of the fused recursion, no merged traversals, row-major tile order, no tile culling / launch rectangle,
-XCD super-tiles, leaf-queue thresholds — for full frames, packed strips and several frames per launch."""
+XCD super-tiles, leaf-queue thresholds, the exact-topology engine alone (wide=0), the XCD-aware tile order, the
+node prefetch — for full frames, packed strips and several frames per launch."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = dict(tile_wlog=1, tile_hlog=3, fused=1, fused_from=0, merge_next=1, tile_order=1, tile_cull=1, launch_rect=1,
-                super_log=0, leaf_flush=16, min_waves=4096)
+DEFAULTS = dict(tile_wlog=2, tile_hlog=2, fused=1, fused_from=0, merge_next=1, tile_order=1, tile_cull=1, launch_rect=1,
+                super_log=0, leaf_flush=16, min_waves=4096, wide=1, xcd_order=1, xcd_block=4, prefetch=0)
 SETTINGS = [
     dict(tile_wlog=3, tile_hlog=3), dict(tile_wlog=2, tile_hlog=3), dict(tile_wlog=3, tile_hlog=2),
-    dict(tile_wlog=2, tile_hlog=2), dict(tile_wlog=0, tile_hlog=0), dict(tile_wlog=3, tile_hlog=0), dict(tile_wlog=0, tile_hlog=3),
+    dict(tile_wlog=1, tile_hlog=3), dict(tile_wlog=0, tile_hlog=0), dict(tile_wlog=3, tile_hlog=0), dict(tile_wlog=0, tile_hlog=3),
     dict(fused=0), dict(fused_from=1), dict(fused_from=2, tile_wlog=3, tile_hlog=3), dict(merge_next=0),
     dict(tile_order=0), dict(tile_cull=0), dict(launch_rect=0), dict(tile_cull=0, launch_rect=0, tile_order=0),
     dict(super_log=1), dict(leaf_flush=1), dict(leaf_flush=32, tile_wlog=3, tile_hlog=3), dict(leaf_flush=36), dict(leaf_flush=4, tile_wlog=3, tile_hlog=3), dict(min_waves=1),
+    dict(wide=0), dict(xcd_order=0), dict(xcd_order=0, tile_wlog=3, tile_hlog=3), dict(prefetch=1), dict(xcd_block=0, prefetch=1, launch_rect=0), dict(xcd_block=6),
 ]
 
 
