@@ -71,8 +71,11 @@ struct WideWalk {
                 const bool done = any & (bk != kNoHit);
                 if (j < cnt && !done) {
                     const uint32_t slot = g * 4u + j, off = slot * 48u;
+                    // the index rides along with the triangle (issued first, so that it costs no round trip of its
+                    // own when the triangle turns out to be a contender; the asm keeps the load from sinking there)
+                    uint32_t idx = __builtin_amdgcn_raw_buffer_load_b32(index, slot * 4u, 0, 0);
                     const float4 c0 = buf_load16(leaf, off), c1 = buf_load16(leaf, off + 16u), c2 = buf_load16(leaf, off + 32u);
-                    const uint32_t idx = __builtin_amdgcn_raw_buffer_load_b32(index, slot * 4u, 0, 0);
+                    asm volatile("" : "+v"(idx));
                     const float4 a = L.rayA[r];
                     RayL ray;
                     ray.o = mk(a.x, a.y, a.z), ray.d = mk(a.w, rb.x, rb.y);
@@ -92,6 +95,26 @@ struct WideWalk {
             wave_lds_fence();
         }
         lq_n = 0;
+    }
+
+    // the lanes' hit leaf children (up to four each) appended to the leaf queue: one prefix sum over the lanes'
+    // counts (three ballots: the bits of a count 0..4) instead of one ballot + prefix per child
+    RT_DEV void queue_leaves4(const bool lf[4], uint32_t r, const uint32_t ref[4])
+    {
+        const uint32_t c = (uint32_t)lf[0] + (uint32_t)lf[1] + (uint32_t)lf[2] + (uint32_t)lf[3];
+        const uint64_t any = ballot(c != 0u);
+        if (any == 0)
+            return;
+        const uint64_t b0 = ballot((c & 1u) != 0u), b1 = ballot((c & 2u) != 0u), b2 = ballot((c & 4u) != 0u);
+        uint32_t o = lq_n + prefix_count(b0) + 2u * prefix_count(b1) + 4u * prefix_count(b2);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (lf[k]) { // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
+                L.wlq[o] = (ref[k] & 0xffffffu) | (((ref[k] >> 29) & 3u) << 24) | (r << 26);
+                o++;
+            }
+        }
+        lq_n += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) + 4u * (uint32_t)__builtin_popcountll(b2);
     }
 
     RT_DEV void queue_leaf(bool want, uint32_t r, uint32_t ref)
@@ -221,16 +244,19 @@ struct WideWalk {
                         near = better ? k : near;
                         near_lb = better ? lbk[k] : near_lb;
                     }
+                    // room for the (up to three) others? otherwise the exact engine traces this ray — its entries here are
+                    // dropped, the result is discarded anyway
+                    if (sp + 3u > kWideStack && ((int)in[0] + (int)in[1] + (int)in[2] + (int)in[3] - (near >= 0 ? 1 : 0)) + (int)sp > (int)kWideStack) {
+                        flag_fallback(r);
+                        near = -1;
+                        in[0] = in[1] = in[2] = in[3] = false;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (in[k] & (k != near)) {
-                            if (sp < kWideStack) {
-                                L.wstack[sp][lane] = (ref[k] << 6) | r;
-                                L.wstack_lb[sp][lane] = (uint16_t)lb_to_u16(lbk[k]);
-                                sp++;
-                            } else {
-                                flag_fallback(r); // no room: the exact engine traces this ray
-                            }
+                            L.wstack[sp][lane] = (ref[k] << 6) | r;
+                            L.wstack_lb[sp][lane] = (uint16_t)lb_to_u16(lbk[k]);
+                            sp++;
                         }
                     }
                     if (near >= 0) {
@@ -243,9 +269,7 @@ struct WideWalk {
                     }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                queue_leaf(lf[k], r, ref[k]);
+            queue_leaves4(lf, r, ref);
             if (lq_n >= flush_at)
                 flush_leaves();
         }
