@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_last_error", "rt_device_info", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
-    "rt_render_device", "rt_render_device_frames", "rt_render_frames", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
+    "rt_render_device", "rt_render_device_frames", "rt_render_frames", "rt_render_sharded", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
     "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_profile_read_launches", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
     "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp", "rt_bloom_device",
 ]
@@ -137,6 +137,8 @@ class Library:
                                               C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p]
         c.rt_render_frames.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.c_int32, C.POINTER(abi.Features),
                                        C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_void_p]
+        c.rt_render_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(abi.Camera), C.POINTER(abi.Features),
+                                        C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         c.rt_render_hits.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Features), C.c_int32,
                                      C.c_int32, C.c_void_p, C.c_void_p]
         c.rt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(abi.Features),
@@ -269,6 +271,17 @@ class Library:
             rows_arr.ctypes.data if rows_arr is not None else None, n_rows, 1 if packed else 0,
             C.c_void_p(rgb_ptr), C.c_void_p(counters_ptr) if counters_ptr else None,
             C.c_void_p(stream) if stream else None))
+
+    # -- one frame on several devices / shards from one process (≙ the C++ host's multi-GPU path)
+    def render_sharded(self, bvhs, cam, features, params, width, height, strip_rows=8, out_ptr: int = 0):
+        """bvhs: one Bvh per shard, each built on its shard's device. Returns the (H, W, 3) host frame, or writes
+        to device memory of shard 0's device when out_ptr is given."""
+        arr = (C.c_void_p * len(bvhs))(*[b.handle for b in bvhs])
+        rgb = None if out_ptr else np.zeros((height, width, 3), np.float32)
+        self._check(self.c.rt_render_sharded(arr, len(bvhs), C.byref(cam), C.byref(features), C.byref(params), width,
+                                             height, strip_rows, C.c_void_p(out_ptr) if out_ptr else rgb.ctypes.data,
+                                             1 if out_ptr else 0))
+        return rgb
 
     # -- several cameras at once into host memory: (n, H, W, 3)
     def render_frames(self, bvh: Bvh, cams, features, params, width, height, out=None):

@@ -151,6 +151,18 @@ struct rt_bvh {
 #endif
     std::mutex mu;
     bool profile = false;
+    // rt_render_sharded: this handle's own stream on its device, the packed strips it renders, and (shard 0) the
+    // gathered strips + assembled frame
+    hipStream_t shard_stream = nullptr;
+    hipEvent_t shard_done = nullptr;
+    DevBuf<float> shard_packed, shard_gathered, shard_frame;
+    ~rt_bvh()
+    {
+        if (shard_done)
+            (void)hipEventDestroy(shard_done);
+        if (shard_stream)
+            (void)hipStreamDestroy(shard_stream);
+    }
     std::map<void*, std::unique_ptr<Scratch>> scratch; // keyed by stream
     Scratch& scratch_for(void* stream)
     {
@@ -1170,6 +1182,90 @@ int rt_render_frames(const rt_bvh* cbvh, const rt_camera* cameras, int32_t n_fra
         HIP_TRY(hipMemcpy(rgb + (size_t)k0 * frame_floats, sc.frame.p, frame_floats * (size_t)n * sizeof(float),
             hipMemcpyDeviceToHost));
     }
+    return RT_OK;
+}
+
+int rt_render_sharded(rt_bvh* const* bvhs, int32_t n_shards, const rt_camera* camera, const rt_features* features,
+    const rt_render_params* params, int32_t width, int32_t height, int32_t strip_rows, float* rgb, int32_t rgb_on_device)
+{
+    if (!bvhs || n_shards < 1 || !camera || !rgb)
+        return fail(RT_ERR_INVALID, "rt_render_sharded: null argument / no shard");
+    if (width <= 0 || height <= 0 || strip_rows <= 0 || (int64_t)width * height > (int64_t)1 << 30)
+        return fail(RT_ERR_INVALID, "rt_render_sharded: bad resolution / strip height");
+    for (int32_t s = 0; s < n_shards; s++)
+        if (!bvhs[s])
+            return fail(RT_ERR_INVALID, "rt_render_sharded: null bvh");
+    int rc = check_features(features, bvhs[0]);
+    if (rc == RT_OK)
+        rc = check_params(params);
+    if (rc != RT_OK)
+        return rc;
+    std::lock_guard<std::mutex> g(g_host_call_mu);
+    int caller_device = 0;
+    HIP_TRY(hipGetDevice(&caller_device));
+    struct Restore {
+        int d;
+        ~Restore() { (void)hipSetDevice(d); }
+    } restore { caller_device };
+    const int dev0 = bvhs[0]->scene->device;
+    const int32_t n_strips = (height + strip_rows - 1) / strip_rows;
+    const int32_t rows_max = ((n_strips + n_shards - 1) / n_shards) * strip_rows;
+    const size_t shard_floats = (size_t)rows_max * width * 3, frame_floats = (size_t)width * height * 3;
+    // the strips are rendered without the whole-frame filter; it runs on the assembled frame
+    rt_features f_strips = *features;
+    f_strips.enableBloomEffect = 0;
+
+    rt_bvh* b0 = bvhs[0];
+    HIP_TRY(hipSetDevice(dev0));
+    if (!b0->shard_stream)
+        HIP_TRY(hipStreamCreateWithFlags(&b0->shard_stream, hipStreamNonBlocking));
+    HIP_TRY(b0->shard_gathered.reserve(shard_floats * (size_t)n_shards));
+    HIP_TRY(b0->shard_frame.reserve(frame_floats));
+    // ---- every shard: its strips into its packed buffer, then a peer copy into shard 0's gathered buffer ----
+    for (int32_t s = 0; s < n_shards; s++) {
+        rt_bvh* b = bvhs[s];
+        const int dev = b->scene->device;
+        HIP_TRY(hipSetDevice(dev));
+        if (dev != dev0) { // peer access both ways, once (an already-enabled pair is not an error here)
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, dev, dev0) == hipSuccess && can)
+                (void)hipDeviceEnablePeerAccess(dev0, 0);
+            (void)hipGetLastError();
+        }
+        if (!b->shard_stream)
+            HIP_TRY(hipStreamCreateWithFlags(&b->shard_stream, hipStreamNonBlocking));
+        if (!b->shard_done)
+            HIP_TRY(hipEventCreateWithFlags(&b->shard_done, hipEventDisableTiming));
+        HIP_TRY(b->shard_packed.reserve(shard_floats));
+        std::vector<int32_t> rows;
+        for (int32_t k = s; k < n_strips; k += n_shards)
+            for (int32_t y = k * strip_rows; y < std::min((k + 1) * strip_rows, height); y++)
+                rows.push_back(y);
+        if (!rows.empty()) {
+            rc = rt_render_device(b, camera, &f_strips, params, width, height, rows.data(), (int32_t)rows.size(), 1,
+                b->shard_packed.p, nullptr, b->shard_stream);
+            if (rc != RT_OK)
+                return rc;
+            HIP_TRY(hipMemcpyPeerAsync(b0->shard_gathered.p + (size_t)s * shard_floats, dev0, b->shard_packed.p, dev,
+                rows.size() * (size_t)width * 3 * sizeof(float), b->shard_stream));
+        }
+        HIP_TRY(hipEventRecord(b->shard_done, b->shard_stream));
+    }
+    // ---- shard 0's device: wait for every shard's copy, de-interleave, filter, hand the frame over ----------
+    HIP_TRY(hipSetDevice(dev0));
+    for (int32_t s = 1; s < n_shards; s++)
+        HIP_TRY(hipStreamWaitEvent(b0->shard_stream, bvhs[s]->shard_done, 0));
+    float* frame = rgb_on_device ? rgb : b0->shard_frame.p;
+    rt::launch_deinterleave(b0->shard_gathered.p, frame, width, height, strip_rows, n_shards, 1, 1, b0->shard_stream);
+    HIP_TRY(hipGetLastError());
+    if (features->enableBloomEffect) {
+        rc = enqueue_bloom(b0->scratch_for(b0->shard_stream), frame, width, height, *params, b0->shard_stream);
+        if (rc != RT_OK)
+            return rc;
+    }
+    if (!rgb_on_device)
+        HIP_TRY(hipMemcpyAsync(rgb, frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, b0->shard_stream));
+    HIP_TRY(hipStreamSynchronize(b0->shard_stream));
     return RT_OK;
 }
 

@@ -119,6 +119,7 @@ struct LaneCounters {
     uint32_t box = 0, tri = 0, sph = 0;     // lane-level tests
     uint32_t grp = 0;                       // lane-level group-box tests (leaf phase)
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
+    uint32_t exact_rays = 0;                // rays this lane's slot sent through the exact-topology engine
 #ifdef RT_TIMELINE
     uint32_t tl_node_iters = 0, tl_leaf_steps = 0, tl_traversals = 0; // wave-uniform step counts (diagnostic)
 #endif

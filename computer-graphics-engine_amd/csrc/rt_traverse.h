@@ -467,6 +467,8 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
 #endif
 
     if (!use_bvh || sv.root_cnt != 0u) { // the root is a leaf / brute force: one ungrouped range per ray
+        if (COUNT && active)
+            lc.exact_rays++;
         w.queue_leaves(active, lane, use_bvh ? sv.root_ref : 0u, use_bvh ? sv.root_cnt : cw_make_big(sv.n_prims), 0.0f);
     } else if (prune && sv.wide_ok != 0u) {
         // The wide engine (rt_wide.h) for the rays it is proven for; the exact-topology engine for the others
@@ -474,6 +476,8 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
         const bool fast = active && inv.all_ok();
         const uint64_t back = traverse_wide<MODE, COUNT>(sv, fast, ray, inv, lc, L, lane);
         const bool slow = active && (!fast || ((back >> lane) & 1ull) != 0ull);
+        if (COUNT && slow)
+            lc.exact_rays++;
         if (ballot(slow)) {
             if (slow)
                 L.best[lane] = kNoHit;
@@ -481,6 +485,8 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
             w.lane_engine(0u, slow, sv.root_ref, 0.0f);
         }
     } else { // the root's own box is never tested (bvh.cpp:313)
+        if (COUNT && active)
+            lc.exact_rays++;
         w.lane_engine(0u, active, sv.root_ref, 0.0f);
     }
     w.flush_leaves(1u);

@@ -14,6 +14,7 @@
 // blurStrength, bloomScalar, bloomThreshold, bloomDebugOption, glossyReflectionsCap, raysPerReflection,
 // alphaModifier (src/light.cpp:12-13, src/render.cpp:14-25) and areaLightSeed.
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -99,10 +100,16 @@ inline rt_render_params params_for(int depth)
     return p;
 }
 
-// What stands behind a BvhInterface: the device scene + BVH handles of the C ABI
+// What stands behind a BvhInterface: the device scene + BVH handles of the C ABI — one pair per shard. With
+// several GPUs visible every GPU gets a copy of the scene and its BVH, and a frame is rendered by all of them
+// (rt_render_sharded: strips of 8 rows dealt round-robin, gathered on the first GPU) — the reference's OpenMP row
+// loop (src/render.cpp:277-281) spread over the node's GPUs. RT_WHITTED_SHARDS=n overrides the shard count
+// (shard s lives on device s % visible devices; two shards on one GPU rehearse the path on a one-GPU box).
 struct Handles {
-    rt_scene* scene = nullptr;
-    rt_bvh* bvh = nullptr;
+    std::vector<rt_scene*> scenes; // [0] serves the single-ray calls
+    std::vector<rt_bvh*> bvhs;
+    rt_scene* scene = nullptr;     // = scenes[0]
+    rt_bvh* bvh = nullptr;         // = bvhs[0]
     Scene* source = nullptr; // borrowed, like m_pScene (bounding_volume_hierarchy.h:86)
     std::vector<rt_light_desc> lights;
     std::vector<std::shared_ptr<Image>> textures; // texture index → the mesh's kdTexture
@@ -112,10 +119,10 @@ struct Handles {
     Handles& operator=(const Handles&) = delete;
     ~Handles()
     {
-        if (bvh)
-            rt_bvh_destroy(bvh);
-        if (scene)
-            rt_scene_destroy(scene);
+        for (rt_bvh* b : bvhs)
+            rt_bvh_destroy(b);
+        for (rt_scene* sc : scenes)
+            rt_scene_destroy(sc);
     }
     // the GUI edits scene.lights between frames (src/main.cpp:296-368)
     void sync_lights()
@@ -123,9 +130,19 @@ struct Handles {
         std::vector<rt_light_desc> now = flatten_lights(*source);
         if (now.size() != lights.size()
             || (!now.empty() && memcmp(now.data(), lights.data(), now.size() * sizeof(rt_light_desc)) != 0)) {
-            check(rt_scene_update_lights(scene, now.data(), (uint32_t)now.size()), "rt_scene_update_lights");
+            for (rt_scene* sc : scenes)
+                check(rt_scene_update_lights(sc, now.data(), (uint32_t)now.size()), "rt_scene_update_lights");
             lights.swap(now);
         }
+    }
+    static int shard_count(int& n_devices)
+    {
+        n_devices = 0;
+        check(rt_device_info(&n_devices, nullptr, 0), "rt_device_info");
+        int n = n_devices;
+        if (const char* e = std::getenv("RT_WHITTED_SHARDS"))
+            n = std::atoi(e);
+        return n < 1 ? 1 : (n > 64 ? 64 : n);
     }
 
     // ≙ BoundingVolumeHierarchy::BoundingVolumeHierarchy(Scene*, const Features&) (bvh.cpp:149-194): flatten the
@@ -201,8 +218,19 @@ struct Handles {
     desc.spheres = spheres.data(), desc.n_spheres = (uint32_t)spheres.size();
     desc.lights = im.lights.data(), desc.n_lights = (uint32_t)im.lights.size();
     desc.textures = textures.data(), desc.n_textures = (uint32_t)textures.size();
-    check(rt_scene_create(&desc, &im.scene), "rt_scene_create");
-    check(rt_bvh_build(im.scene, reinterpret_cast<const rt_features*>(&features), &im.bvh), "rt_bvh_build");
+    int n_devices = 0;
+    const int n_shards = shard_count(n_devices);
+    for (int sh = 0; sh < n_shards; sh++) { // one copy of the scene + BVH per shard, on the shard's device
+        check(rt_set_device(sh % n_devices), "rt_set_device");
+        rt_scene* sc = nullptr;
+        rt_bvh* bv = nullptr;
+        check(rt_scene_create(&desc, &sc), "rt_scene_create");
+        im.scenes.push_back(sc);
+        check(rt_bvh_build(sc, reinterpret_cast<const rt_features*>(&features), &bv), "rt_bvh_build");
+        im.bvhs.push_back(bv);
+    }
+    check(rt_set_device(0), "rt_set_device");
+    im.scene = im.scenes[0], im.bvh = im.bvhs[0];
 }
 
     // ≙ BoundingVolumeHierarchy::intersect (bvh.cpp:299-427) for one ray
@@ -232,9 +260,14 @@ struct Handles {
         sync_lights();
         const glm::ivec2 res = screen.resolution();
         const rt_render_params p = params_for(5); // the literal rayDepth of render.cpp:298,308,318
-        check(rt_render(bvh, &cam, reinterpret_cast<const rt_features*>(&features), &p, res.x, res.y, 0, res.y,
-                  reinterpret_cast<float*>(screen.pixels().data()), nullptr),
-            "rt_render");
+        if (bvhs.size() > 1) // every shard renders its strips, the first one's device assembles the frame
+            check(rt_render_sharded(bvhs.data(), (int32_t)bvhs.size(), &cam, reinterpret_cast<const rt_features*>(&features), &p,
+                      res.x, res.y, 8, reinterpret_cast<float*>(screen.pixels().data()), 0),
+                "rt_render_sharded");
+        else
+            check(rt_render(bvh, &cam, reinterpret_cast<const rt_features*>(&features), &p, res.x, res.y, 0, res.y,
+                      reinterpret_cast<float*>(screen.pixels().data()), nullptr),
+                "rt_render");
     }
 
     // ≙ getFinalColor (render.cpp:152-155) for a batch of rays

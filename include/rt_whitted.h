@@ -188,6 +188,9 @@ typedef struct rt_counters {
     uint64_t group_tests;    /* conservative ray / triangle-group box tests of the leaf phase (pruned policy only) */
     uint64_t rays_culled;    /* primary rays (counted in `rays`) of tiles the timed launch ends in its prologue or never
                               * launches: their ray pyramid misses the scene bounds, so they never touch the BVH */
+    uint64_t rays_exact;     /* rays traced by the exact-topology engine: all of them where the wide tree does not
+                              * apply (spheres, unpruned policy, brute force, tiny scenes), else the rays that are not
+                              * all_ok or that the wide engine handed back (csrc/rt_wide.h) */
 } rt_counters;
 
 typedef struct rt_scene rt_scene; /* opaque */
@@ -283,6 +286,21 @@ int rt_render_device_frames(const rt_bvh* bvh, const rt_camera* cameras, int32_t
                             const rt_features* features, const rt_render_params* params, int32_t width,
                             int32_t height, const int32_t* rows, int32_t n_rows, int32_t packed, float* rgb_dev,
                             uint64_t frame_stride_floats, void* hip_stream);
+
+/* -- One frame on SEVERAL devices from ONE process (the C++ host's multi-GPU path; replaces the reference's
+ *    in-process OpenMP row loop, src/render.cpp:277-281): bvhs[s] is a BVH handle built on the device shard s
+ *    renders on (rt_set_device(d) before rt_scene_create / rt_bvh_build; the scene and BVH are replicated, one
+ *    copy per device; two shards may share a device). The frame's strips of `strip_rows` image rows are dealt
+ *    round-robin to the shards (strip k -> shard k % n_shards: balances an object in the middle of the frame),
+ *    every shard renders its strips into a packed buffer on its own device and stream, the packed strips are
+ *    gathered on shard 0's device by peer copies (hipMemcpyPeerAsync — xGMI between the GPUs of a node) and
+ *    de-interleaved there into the reference's row-flipped frame. The area-light RNG is keyed by the global pixel
+ *    id: the image does not depend on n_shards. renderBloomFilter (whole-frame) runs on the assembled frame.
+ *    rgb: width * height * 3 floats — host memory when rgb_on_device == 0, else memory of shard 0's device.
+ *    Enqueues all shards before it waits for any; returns when the frame is complete. ------------------------ */
+int rt_render_sharded(rt_bvh* const* bvhs, int32_t n_shards, const rt_camera* camera, const rt_features* features,
+                      const rt_render_params* params, int32_t width, int32_t height, int32_t strip_rows, float* rgb,
+                      int32_t rgb_on_device);
 
 /* -- The same into host memory: n_frames row-flipped frames of width * height * 3 floats, one after the other
  *    in rgb (what n calls of rt_render would write, one camera each). ----------------------------------- */

@@ -103,6 +103,18 @@ def make_flags(rng, scene):
     return f, p
 
 
+def _progress(name, case, n_cases, bad, t_start):
+    """campaigns (FUZZ_CASES in the thousands) report every 50 cases to FUZZ_PROGRESS (a file under gpurun_out/ keeps
+    a long run from looking hung) and to stdout"""
+    if (case + 1) % 50 == 0 or case + 1 == n_cases:
+        line = f"{name}: {case + 1}/{n_cases} cases, {len(bad)} mismatches, {time.time() - t_start:.0f} s"
+        print(line, flush=True)
+        path = os.environ.get("FUZZ_PROGRESS")
+        if path:
+            with open(path, "a") as fh:
+                fh.write(line + "\n")
+
+
 def test_random_scenes_match_oracle(rt, oracle, abi):
     globals()["abi"] = abi
     n_cases = int(os.environ.get("FUZZ_CASES", "60"))
@@ -110,6 +122,7 @@ def test_random_scenes_match_oracle(rt, oracle, abi):
     orc = oracle
     bad = []
     t_start = time.time()
+    rays_all = rays_exact = wide_cases = 0
     for case in range(n_cases):
         seed = seed0 + case
         rng = np.random.default_rng(seed)
@@ -123,6 +136,8 @@ def test_random_scenes_match_oracle(rt, oracle, abi):
         try:
             bvh, ob = rt.bvh(rt.scene(scene), f), orc.build(scene, f)
             rgb, cnt = rt.render(bvh, rt.camera(*cam_args), f, p, W, H, count=True)
+            rays_all, rays_exact = rays_all + cnt.rays, rays_exact + cnt.rays_exact
+            wide_cases += 1 if cnt.rays_exact < cnt.rays else 0
             want_hits = not (flags["enableMultipleRaysPerPixel"] or flags["enableDepthOfField"])
             orgb, otb, opr, ocnt = orc.render(ob, orc.camera(*cam_args), f, p, W, H, want_hits=want_hits)
             if want_hits:
@@ -147,8 +162,10 @@ def test_random_scenes_match_oracle(rt, oracle, abi):
             bad.append(f"seed {seed} {W}x{H} tris {scene.n_triangles} spheres {len(scene.spheres)} {on} {params}: "
                        + "; ".join(msg))
             print("MISMATCH", bad[-1], flush=True)
-        if case % 50 == 49:
-            print(f"... {case + 1} cases, {len(bad)} bad, {time.time() - t_start:.0f} s", flush=True)
+        _progress("random scenes", case, n_cases, bad, t_start)
+    print(f"random scenes: {rays_all} rays, {rays_all - rays_exact} through the wide engine ({wide_cases} of {n_cases} cases), "
+          f"{rays_exact} through the exact-topology engine", flush=True)
+    assert wide_cases > n_cases // 10, "the campaign must exercise the wide engine"
     assert not bad, f"{len(bad)} of {n_cases} random cases differ:\n" + "\n".join(bad[:10])
 
 
@@ -260,8 +277,7 @@ def test_adversarial_rays_intersect_and_trace(rt, oracle, abi):
             on = [k for k, v in flags.items() if v]
             bad.append(f"seed {seed} tris {scene.n_triangles} spheres {len(scene.spheres)} {on} {params}: " + "; ".join(msg))
             print("MISMATCH", bad[-1], flush=True)
-        if case % 25 == 24:
-            print(f"... {case + 1} cases, {len(bad)} bad, {time.time() - t_start:.0f} s", flush=True)
+        _progress("adversarial rays", case, n_cases, bad, t_start)
     print(f"adversarial rays: {n_rays} rays, {n_hits} hits, {n_lit} non-black colours", flush=True)
     assert n_hits > n_rays // 20 and n_lit > n_rays // 50, "the rays must hit and light something"
     assert not bad, f"{len(bad)} of {n_cases} adversarial-ray cases differ:\n" + "\n".join(bad[:10])

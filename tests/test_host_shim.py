@@ -44,7 +44,14 @@ def write_scene_file(path, abi, scene, features, cam_args, rays, depth):
 
 
 @pytest.mark.gpu
-def test_shim_matches_c_abi(rt, abi, scenes, tmp_path):
+@pytest.mark.parametrize("shards", [None, 3], ids=["one-shard-per-device", "three-shards"])
+def test_shim_matches_c_abi(rt, abi, scenes, tmp_path, shards):
+    """shards = 3: RT_WHITTED_SHARDS makes the shim's renderRayTracing take its multi-GPU path (rt_render_sharded:
+    three copies of the scene, strips dealt round-robin, gathered on the first) on the one GPU of the box."""
+    import os
+    env = dict(os.environ)
+    if shards:
+        env["RT_WHITTED_SHARDS"] = str(shards)
     subprocess.run(["make", "-C", str(HOST)], check=True, capture_output=True)
     # textured cube + monkey in one Scene (two meshes, one texture, specular materials)
     cube, monkey = scenes.load_fixture_scene("cube_textured"), scenes.load_fixture_scene("monkey")
@@ -64,7 +71,7 @@ def test_shim_matches_c_abi(rt, abi, scenes, tmp_path):
     rays["t"] = np.float32(3.402823466e+38)
     write_scene_file(tmp_path / "scene.bin", abi, scene, f, cam_args, rays, depth)
     r = subprocess.run([str(HOST / "shim_selftest"), str(tmp_path / "scene.bin"), str(tmp_path / "out.bin"), str(W),
-                        str(H)], capture_output=True, text=True)
+                        str(H)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = (tmp_path / "out.bin").read_bytes()
     w, h, levels, leaves = struct.unpack("<4i", raw[:16])
