@@ -49,6 +49,54 @@ struct BNode { // binary build node
     uint32_t beg = 0, cnt = 0;     // triangle range (leaf)
 };
 
+// a node's children with full-precision bounds, before quantisation
+struct FNode {
+    float lo[4][3], hi[4][3];
+    uint32_t ref[4];
+};
+
+// WideNode from full-precision child bounds: offsets rounded outward (rt_layout.h)
+WideNode quantise(const FNode& f)
+{
+    WideNode q;
+    memset(&q, 0, sizeof(q));
+    for (int a = 0; a < 3; a++) {
+        float lo = FLT_MAX, hi = -FLT_MAX;
+        for (int k = 0; k < 4; k++)
+            if (f.ref[k] != kWideEmpty)
+                lo = std::min(lo, f.lo[k][a]), hi = std::max(hi, f.hi[k][a]);
+        if (lo > hi)
+            lo = hi = 0.0f;
+        // the smallest power of two with 255 steps covering the extent (computed in double, checked below)
+        const double ext = (double)hi - (double)lo;
+        int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+        e = std::max(-126, std::min(127, e));
+        while (e < 127 && std::ldexp(255.0, e) < ext)
+            e++;
+        const double scale = std::ldexp(1.0, e);
+        q.origin[a] = lo;
+        q.exps |= (uint32_t)(e + 127) << (8 * a);
+        for (int k = 0; k < 4; k++) {
+            uint32_t ql = 0, qh = 0;
+            if (f.ref[k] != kWideEmpty) {
+                ql = (uint32_t)std::max(0.0, std::min(255.0, std::floor(((double)f.lo[k][a] - lo) / scale)));
+                qh = (uint32_t)std::max(0.0, std::min(255.0, std::ceil(((double)f.hi[k][a] - lo) / scale)));
+                // outward: lo + ql * scale <= child lo and lo + qh * scale >= child hi, exactly (all terms are doubles
+                // with few significant bits)
+                while (ql > 0 && (double)lo + ql * scale > (double)f.lo[k][a])
+                    ql--;
+                while (qh < 255 && (double)lo + qh * scale < (double)f.hi[k][a])
+                    qh++;
+            }
+            q.qlo[a] |= ql << (8 * k);
+            q.qhi[a] |= qh << (8 * k);
+        }
+    }
+    for (int k = 0; k < 4; k++)
+        q.ref[k] = f.ref[k];
+    return q;
+}
+
 constexpr int kBins = 16;
 constexpr uint32_t kLeafMax = 4;
 
@@ -197,17 +245,14 @@ void HostBvh::build_wide()
             kids[pick] = b.bn[open].left;
             kids[nk++] = b.bn[open].right;
         }
-        WideNode wn;
+        FNode wn;
         memset(&wn, 0, sizeof(wn));
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 4; k++)
             wn.ref[k] = kWideEmpty;
-            wn.lox[k] = wn.loy[k] = wn.loz[k] = FLT_MAX; // an empty slot is masked by its reference word
-            wn.hix[k] = wn.hiy[k] = wn.hiz[k] = FLT_MAX;
-        }
         for (int k = 0; k < nk; k++) {
             const BNode& c = b.bn[kids[k]];
-            wn.lox[k] = c.box.lo[0], wn.loy[k] = c.box.lo[1], wn.loz[k] = c.box.lo[2];
-            wn.hix[k] = c.box.hi[0], wn.hiy[k] = c.box.hi[1], wn.hiz[k] = c.box.hi[2];
+            for (int a = 0; a < 3; a++)
+                wn.lo[k][a] = c.box.lo[a], wn.hi[k][a] = c.box.hi[a];
             if (c.left < 0) { // leaf group
                 if (n_groups >= kWideMaxGroups)
                     return;
@@ -231,7 +276,7 @@ void HostBvh::build_wide()
                 todo.push_back({ kids[k], wn.ref[k], it.depth + 1 });
             }
         }
-        wide_nodes[it.wnode] = wn;
+        wide_nodes[it.wnode] = quantise(wn);
     }
     wide_ok = true;
 }

@@ -106,19 +106,25 @@ RT_LAYOUT_FN uint32_t cw_make_big(uint32_t count) { return 0x80000000u | (count 
 // on the leaves' triangles, and check a would-be candidate against the exact test of the reference leaf it
 // lives in (the winner only: rt_wide.h). Tie ranks (the index in the reference's visit order) ride along per slot.
 //
-// WideNode: four children, SoA so that one child is one lane of a float4. 128 bytes, 128-byte aligned.
+// WideNode: four children in 56 bytes (64-byte records). The kernel is bound by the bytes that pass through the
+// CUs' vector caches (profiles/r02_notes.md), and its box test is conservative by construction, so the children's
+// bounds are stored as 8-bit offsets inside the node's own box, rounded OUTWARD:
+//     child k, axis a:  lo = origin[a] + qlo[a].byte[k] * 2^(exp[a] - 127),  hi = origin[a] + qhi[a].byte[k] * 2^(exp[a] - 127)
+// (origin = lower corner of the union of the children; 2^(exp - 127) * 255 >= its extent). A quantised box contains
+// the exact one, so no candidate is lost; it is at most 1/255 of the node's extent wider per plane.
 // Child reference word:
 //   0xffffffff          empty slot
 //   bit 31 set          leaf group: bits 30:29 = triangles - 1 (1..4), bits 23:0 = group index;
 //                       group g holds slots [4g, 4g + count) of `wide_leaf` / `wide_index`
 //   otherwise           internal node: index into the WideNode array (< 2^26)
-struct alignas(128) WideNode {
-    float lox[4], loy[4], loz[4];
-    float hix[4], hiy[4], hiz[4];
+struct alignas(64) WideNode {
+    float origin[3];
+    uint32_t exps;             // biased exponents of the three axes' scales: x bits 7:0, y 15:8, z 23:16
+    uint32_t qlo[3], qhi[3];   // per axis: the four children's offsets, child k in byte k
     uint32_t ref[4];
-    uint32_t pad[4];
+    uint32_t pad[2];
 };
-static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
+static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 constexpr uint32_t kWideEmpty = 0xffffffffu;
 constexpr uint32_t kWideMaxNodes = 1u << 26, kWideMaxGroups = 1u << 24;
 RT_LAYOUT_FN bool wide_is_leaf(uint32_t ref) { return (ref >> 31) != 0u; }

@@ -13,10 +13,11 @@
 // is never tested (bvh.cpp:313). So for such a ray
 //     the reference visits a leaf  <=>  T(leaf's own box), unless that test passes with tout == 0,
 // whatever the tree above the leaves looks like. The wide engine therefore
-//   * walks the wide tree with a CONSERVATIVE box test: one FMA per slab plane, the interval widened by the
-//     pruning slack (rt_device.h "Pruning": a candidate's point lies within rho = 2^-16 x scene scale of its
-//     triangle, hence of every box around it; the FMA form adds at most 2^-22 x scale x |1/d| of rounding,
-//     1/64 of the slack), pruned by min(initial ray.t, best t so far) like the exact engine;
+//   * walks the wide tree with a CONSERVATIVE box test: the children's bounds are 8-bit offsets inside the node's
+//     box, rounded outward (rt_layout.h WideNode), one conversion + one FMA per slab plane, the interval widened
+//     by the pruning slack (rt_device.h "Pruning": a candidate's point lies within rho = 2^-16 x scene scale of
+//     its triangle, hence of every box around it; the roundings of the FMA form stay below 1/32 of the slack),
+//     pruned by min(initial ray.t, best t so far) like the exact engine;
 //   * runs the reference's exact triangle test (Appendix A.1/A.2) on the triangles of the leaf groups reached;
 //   * keeps, per ray, the smallest key among ALL triangles that pass that test (wide_index gives a slot's index in
 //     the reference's visit order, so ties resolve as there) and prunes with it;
@@ -198,28 +199,31 @@ struct WideWalk {
                 const float lim = __uint_as_float((any || t0b < bb) ? t0b : bb); // shadow rays: t0; else min(t0, best t)
                 const bool skip = (any & (bk != kNoHit)) | (!any & (e_lb > lim));
                 if (!skip) {
-                    const uint32_t noff = (e >> 6) * 128u;
-                    const float4 lox = buf_load16(nodes, noff), loy = buf_load16(nodes, noff + 16u);
-                    const float4 loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
-                    const float4 hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
-                    const float4 rf = buf_load16(nodes, noff + 96u);
+                    const uint32_t noff = (e >> 6) * 64u;
+                    const float4 w0 = buf_load16(nodes, noff), w1 = buf_load16(nodes, noff + 16u), w2 = buf_load16(nodes, noff + 32u);
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 w3 = __builtin_amdgcn_raw_buffer_load_b64(nodes, noff + 48u, 0, 0);
                     asm volatile("" ::"v"(touched)); // the touch is over by now (loads return in order)
-                    ref[0] = __float_as_uint(rf.x), ref[1] = __float_as_uint(rf.y);
-                    ref[2] = __float_as_uint(rf.z), ref[3] = __float_as_uint(rf.w);
-                    // t = b * (1/d) - o * (1/d): one FMA per slab plane; s covers its rounding and the box growth rho
+                    ref[0] = __float_as_uint(w2.z), ref[1] = __float_as_uint(w2.w), ref[2] = w3.x, ref[3] = w3.y;
+                    // Child plane: b = origin + q * 2^(exp - 127); t = b * (1/d) - o * (1/d) = q * (scale / d) + (origin - o) / d:
+                    // one conversion and one FMA per plane. s covers the roundings (each below 2^-21 x scene scale x |1/d|,
+                    // 1/32 of the slack) and the box growth rho.
                     const float s = rc.w * 1.0625f;
-                    const float ox = ra.x * rc.x, oy = ra.y * rc.y, oz = ra.z * rc.z;
+                    const uint32_t ex = __float_as_uint(w0.w);
+                    const float sx = __uint_as_float((ex & 0xffu) << 23) * rc.x, sy = __uint_as_float(((ex >> 8) & 0xffu) << 23) * rc.y;
+                    const float sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rc.z;
+                    const float ox = (w0.x - ra.x) * rc.x, oy = (w0.y - ra.y) * rc.y, oz = (w0.z - ra.z) * rc.z;
                     const float s2 = s + s, ms = -s, lims = lim + s;
-                    const float bx0[4] = { lox.x, lox.y, lox.z, lox.w }, bx1[4] = { hix.x, hix.y, hix.z, hix.w };
-                    const float by0[4] = { loy.x, loy.y, loy.z, loy.w }, by1[4] = { hiy.x, hiy.y, hiy.z, hiy.w };
-                    const float bz0[4] = { loz.x, loz.y, loz.z, loz.w }, bz1[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+                    const uint32_t qx0 = __float_as_uint(w1.x), qy0 = __float_as_uint(w1.y), qz0 = __float_as_uint(w1.z);
+                    const uint32_t qx1 = __float_as_uint(w1.w), qy1 = __float_as_uint(w2.x), qz1 = __float_as_uint(w2.y);
+                    auto byte_f = [](uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }; // v_cvt_f32_ubyteK
                     bool in[4];
                     float lbk[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const float tx0 = __builtin_fmaf(bx0[k], rc.x, -ox), tx1 = __builtin_fmaf(bx1[k], rc.x, -ox);
-                        const float ty0 = __builtin_fmaf(by0[k], rc.y, -oy), ty1 = __builtin_fmaf(by1[k], rc.y, -oy);
-                        const float tz0 = __builtin_fmaf(bz0[k], rc.z, -oz), tz1 = __builtin_fmaf(bz1[k], rc.z, -oz);
+                        const float tx0 = __builtin_fmaf(byte_f(qx0, k), sx, ox), tx1 = __builtin_fmaf(byte_f(qx1, k), sx, ox);
+                        const float ty0 = __builtin_fmaf(byte_f(qy0, k), sy, oy), ty1 = __builtin_fmaf(byte_f(qy1, k), sy, oy);
+                        const float tz0 = __builtin_fmaf(byte_f(qz0, k), sz, oz), tz1 = __builtin_fmaf(byte_f(qz1, k), sz, oz);
                         const float tin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
                         const float tout = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
                         // may the ray pass within the slack of the box at a distance in [0, lim]? (positive comparisons:
@@ -265,7 +269,7 @@ struct WideWalk {
                         e_lb = near_lb;
                         have = true;
                         if (prefetch) // bring the next node's line towards this CU while the step's bookkeeping runs
-                            touched = __builtin_amdgcn_raw_buffer_load_b32(nodes, nref * 128u, 0, 0);
+                            touched = __builtin_amdgcn_raw_buffer_load_b32(nodes, nref * 64u, 0, 0);
                     }
                 }
             }
@@ -308,7 +312,7 @@ RT_DEV uint64_t traverse_wide(const SceneView& sv, bool fast, const RayL& ray, c
     WaveLds& L, uint32_t lane)
 {
     uint32_t flush_at = sv.leaf_flush < kWideFlushMax ? sv.leaf_flush : kWideFlushMax;
-    WideWalk<MODE, COUNT> w { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 128u),
+    WideWalk<MODE, COUNT> w { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 64u),
         make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u), 0u,
         flush_at < 1u ? 1u : flush_at };
     uint64_t back = w.run(fast);

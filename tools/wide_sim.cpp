@@ -96,7 +96,12 @@ static void trace_wide(const HostBvh& b, const Ray& r, bool any_hit, double tmax
             if (n.ref[k] == kWideEmpty)
                 continue;
             st.child_tests++;
-            const float lo[3] = { n.lox[k], n.loy[k], n.loz[k] }, hi[3] = { n.hix[k], n.hiy[k], n.hiz[k] };
+            float lo[3], hi[3]; // the quantised bounds the kernel sees (rt_layout.h WideNode)
+            for (int a = 0; a < 3; a++) {
+                const float scale = std::ldexp(1.0f, (int)((n.exps >> (8 * a)) & 0xffu) - 127);
+                lo[a] = n.origin[a] + (float)((n.qlo[a] >> (8 * k)) & 0xffu) * scale;
+                hi[a] = n.origin[a] + (float)((n.qhi[a] >> (8 * k)) & 0xffu) * scale;
+            }
             double tin;
             if (!slab(lo, hi, r, best, tin))
                 continue;
