@@ -857,7 +857,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         const LaneCounters* lc;
         __device__ ~TimelineEnd()
         {
-            if (p && lane == 0 && wave < (1u << 17)) {
+            if (p && lc && lane == 0 && wave < (1u << 17)) { // lc == NULL: the wave left before it had any work
                 uint32_t hw;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
                 uint32_t xcc;

@@ -1,4 +1,4 @@
-// rt_wide.h — the wide engine: traversal of our own 4-wide SAH tree (rt_layout.h WideNode, host_wide.cpp)
+// rt_wide.h — the wide engine: traversal of our own 8-wide SAH tree (rt_layout.h WideNode, host_wide.cpp)
 // that returns the bits of the reference's traversal of ITS tree.
 //
 // Why a different tree may be walked. For a ray whose three direction components are non-zero, finite and of
@@ -98,34 +98,27 @@ struct WideWalk {
         lq_n = 0;
     }
 
-    // the lanes' hit leaf children (up to four each) appended to the leaf queue: one prefix sum over the lanes'
-    // counts (three ballots: the bits of a count 0..4) instead of one ballot + prefix per child
-    RT_DEV void queue_leaves4(const bool lf[4], uint32_t r, const uint32_t ref[4])
+    // Hit leaf children k0 .. k0 + 3 of every lane (`four`: their hit bits) appended to the leaf queue: one prefix sum
+    // over the lanes' counts (three ballots: the bits of a count 0..4) instead of one ballot + prefix per child.
+    // Child k is the (leaf children before k)-th group from base_group; entry: group | (triangles - 1) << 24 | ray << 26.
+    RT_DEV void queue_leaves4(uint32_t four, int k0, uint32_t r, uint32_t base_group, uint32_t counts, uint32_t leaf_mask)
     {
-        const uint32_t c = (uint32_t)lf[0] + (uint32_t)lf[1] + (uint32_t)lf[2] + (uint32_t)lf[3];
+        const uint32_t c = (uint32_t)__builtin_popcount(four);
         const uint64_t any = ballot(c != 0u);
         if (any == 0)
             return;
         const uint64_t b0 = ballot((c & 1u) != 0u), b1 = ballot((c & 2u) != 0u), b2 = ballot((c & 4u) != 0u);
         uint32_t o = lq_n + prefix_count(b0) + 2u * prefix_count(b1) + 4u * prefix_count(b2);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (lf[k]) { // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
-                L.wlq[o] = (ref[k] & 0xffffffu) | (((ref[k] >> 29) & 3u) << 24) | (r << 26);
+        for (int j = 0; j < 4; j++) {
+            if ((four >> j) & 1u) {
+                const int k = k0 + j;
+                const uint32_t group = (base_group & 0xffffffu) + (uint32_t)__builtin_popcount(leaf_mask & ((1u << k) - 1u));
+                L.wlq[o] = group | (((counts >> (2 * k)) & 3u) << 24) | (r << 26);
                 o++;
             }
         }
         lq_n += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) + 4u * (uint32_t)__builtin_popcountll(b2);
-    }
-
-    RT_DEV void queue_leaf(bool want, uint32_t r, uint32_t ref)
-    {
-        const uint64_t m = ballot(want);
-        if (m) {
-            if (want) // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
-                L.wlq[lq_n + prefix_count(m)] = (ref & 0xffffffu) | (((ref >> 29) & 3u) << 24) | (r << 26);
-            lq_n += (uint32_t)__builtin_popcountll(m);
-        }
     }
 
     // ---- node phase: private deques + work stealing, as in the exact engine -------------------------------
@@ -186,8 +179,8 @@ struct WideWalk {
                     wave_lds_fence();
                 }
             }
-            bool lf[4] = { false, false, false, false };
-            uint32_t ref[4] = { 0u, 0u, 0u, 0u };
+            uint32_t leaves = 0u;       // mask of this lane's hit leaf children
+            uint32_t base_group = 0u, counts = 0u, leaf_mask = 0u;
             uint32_t r = 0;
             if (have) {
                 have = false;
@@ -199,12 +192,10 @@ struct WideWalk {
                 const float lim = __uint_as_float((any || t0b < bb) ? t0b : bb); // shadow rays: t0; else min(t0, best t)
                 const bool skip = (any & (bk != kNoHit)) | (!any & (e_lb > lim));
                 if (!skip) {
-                    const uint32_t noff = (e >> 6) * 64u;
+                    const uint32_t noff = (e >> 6) * 128u;
                     const float4 w0 = buf_load16(nodes, noff), w1 = buf_load16(nodes, noff + 16u), w2 = buf_load16(nodes, noff + 32u);
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 w3 = __builtin_amdgcn_raw_buffer_load_b64(nodes, noff + 48u, 0, 0);
+                    const float4 w3 = buf_load16(nodes, noff + 48u), w4 = buf_load16(nodes, noff + 64u);
                     asm volatile("" ::"v"(touched)); // the touch is over by now (loads return in order)
-                    ref[0] = __float_as_uint(w2.z), ref[1] = __float_as_uint(w2.w), ref[2] = w3.x, ref[3] = w3.y;
                     // Child plane: b = origin + q * 2^(exp - 127); t = b * (1/d) - o * (1/d) = q * (scale / d) + (origin - o) / d:
                     // one conversion and one FMA per plane. s covers the roundings (each below 2^-21 x scene scale x |1/d|,
                     // 1/32 of the slack) and the box growth rho.
@@ -214,66 +205,80 @@ struct WideWalk {
                     const float sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rc.z;
                     const float ox = (w0.x - ra.x) * rc.x, oy = (w0.y - ra.y) * rc.y, oz = (w0.z - ra.z) * rc.z;
                     const float s2 = s + s, ms = -s, lims = lim + s;
-                    const uint32_t qx0 = __float_as_uint(w1.x), qy0 = __float_as_uint(w1.y), qz0 = __float_as_uint(w1.z);
-                    const uint32_t qx1 = __float_as_uint(w1.w), qy1 = __float_as_uint(w2.x), qz1 = __float_as_uint(w2.y);
+                    // qlo x: w1.x w1.y, y: w1.z w1.w, z: w2.x w2.y; qhi x: w2.z w2.w, y: w3.x w3.y, z: w3.z w3.w
+                    const uint32_t qx0[2] = { __float_as_uint(w1.x), __float_as_uint(w1.y) }, qy0[2] = { __float_as_uint(w1.z), __float_as_uint(w1.w) };
+                    const uint32_t qz0[2] = { __float_as_uint(w2.x), __float_as_uint(w2.y) }, qx1[2] = { __float_as_uint(w2.z), __float_as_uint(w2.w) };
+                    const uint32_t qy1[2] = { __float_as_uint(w3.x), __float_as_uint(w3.y) }, qz1[2] = { __float_as_uint(w3.z), __float_as_uint(w3.w) };
+                    const uint32_t base_node = __float_as_uint(w4.x), int_mask = ex >> 24;
+                    base_group = __float_as_uint(w4.y), counts = __float_as_uint(w4.z);
+                    leaf_mask = base_group >> 24;
                     auto byte_f = [](uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }; // v_cvt_f32_ubyteK
-                    bool in[4];
-                    float lbk[4];
+                    uint32_t hits = 0u; // children whose (widened) box the ray may pass within [0, lim]
+                    float lbk[8];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const float tx0 = __builtin_fmaf(byte_f(qx0, k), sx, ox), tx1 = __builtin_fmaf(byte_f(qx1, k), sx, ox);
-                        const float ty0 = __builtin_fmaf(byte_f(qy0, k), sy, oy), ty1 = __builtin_fmaf(byte_f(qy1, k), sy, oy);
-                        const float tz0 = __builtin_fmaf(byte_f(qz0, k), sz, oz), tz1 = __builtin_fmaf(byte_f(qz1, k), sz, oz);
+                    for (int k = 0; k < 8; k++) {
+                        const int w = k >> 2, b = k & 3;
+                        const float tx0 = __builtin_fmaf(byte_f(qx0[w], b), sx, ox), tx1 = __builtin_fmaf(byte_f(qx1[w], b), sx, ox);
+                        const float ty0 = __builtin_fmaf(byte_f(qy0[w], b), sy, oy), ty1 = __builtin_fmaf(byte_f(qy1[w], b), sy, oy);
+                        const float tz0 = __builtin_fmaf(byte_f(qz0[w], b), sz, oz), tz1 = __builtin_fmaf(byte_f(qz1[w], b), sz, oz);
                         const float tin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
                         const float tout = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-                        // may the ray pass within the slack of the box at a distance in [0, lim]? (positive comparisons:
-                        // a NaN — impossible for an all_ok ray and a finite box — would drop the child, never a real one)
-                        const bool hit = (tin <= tout + s2) & (tout >= ms) & (tin <= lims) & (ref[k] != kWideEmpty);
+                        // positive comparisons: a NaN — impossible for an all_ok ray and a finite box — would drop the
+                        // child, never a real one; empty children are in neither kind mask
+                        const bool hit = (tin <= tout + s2) & (tout >= ms) & (tin <= lims);
+                        hits |= hit ? (1u << k) : 0u;
                         lbk[k] = tin - s;
-                        lf[k] = hit & wide_is_leaf(ref[k]);
-                        in[k] = hit & !wide_is_leaf(ref[k]);
                     }
+                    leaves = hits & leaf_mask;
+                    uint32_t inner = hits & int_mask;
                     if (COUNT) {
                         lc.node_fetch++;
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            lc.box += ref[k] != kWideEmpty ? 1u : 0u;
+                        lc.box += (uint32_t)__builtin_popcount(int_mask | leaf_mask);
                     }
                     // the nearest internal child becomes the current entry, the others are put aside
                     int near = -1;
                     float near_lb = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool better = in[k] & ((near < 0) | (lbk[k] < near_lb));
+                    for (int k = 0; k < 8; k++) {
+                        const bool better = ((inner >> k) & 1u) & ((near < 0) | (lbk[k] < near_lb));
                         near = better ? k : near;
                         near_lb = better ? lbk[k] : near_lb;
                     }
-                    // room for the (up to three) others? otherwise the exact engine traces this ray — its entries here are
-                    // dropped, the result is discarded anyway
-                    if (sp + 3u > kWideStack && ((int)in[0] + (int)in[1] + (int)in[2] + (int)in[3] - (near >= 0 ? 1 : 0)) + (int)sp > (int)kWideStack) {
+                    // room for the (up to seven) others? otherwise the exact engine traces this ray — its entries here
+                    // are dropped, the result is discarded anyway
+                    const uint32_t n_push = (uint32_t)__builtin_popcount(inner) - (near >= 0 ? 1u : 0u);
+                    if (sp + n_push > kWideStack) {
                         flag_fallback(r);
                         near = -1;
-                        in[0] = in[1] = in[2] = in[3] = false;
+                        inner = 0u;
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (in[k] & (k != near)) {
-                            L.wstack[sp][lane] = (ref[k] << 6) | r;
+                    for (int k = 0; k < 8; k++) {
+                        if (((inner >> k) & 1u) & (k != near)) {
+                            const uint32_t node = base_node + (uint32_t)__builtin_popcount(int_mask & ((1u << k) - 1u));
+                            L.wstack[sp][lane] = (node << 6) | r;
                             L.wstack_lb[sp][lane] = (uint16_t)lb_to_u16(lbk[k]);
                             sp++;
                         }
                     }
                     if (near >= 0) {
-                        const uint32_t nref = near == 0 ? ref[0] : (near == 1 ? ref[1] : (near == 2 ? ref[2] : ref[3]));
-                        e = (nref << 6) | r;
+                        const uint32_t nnode = base_node + (uint32_t)__builtin_popcount(int_mask & ((1u << near) - 1u));
+                        e = (nnode << 6) | r;
                         e_lb = near_lb;
                         have = true;
                         if (prefetch) // bring the next node's line towards this CU while the step's bookkeeping runs
-                            touched = __builtin_amdgcn_raw_buffer_load_b32(nodes, nref * 64u, 0, 0);
+                            touched = __builtin_amdgcn_raw_buffer_load_b32(nodes, nnode * 128u, 0, 0);
                     }
                 }
             }
-            queue_leaves4(lf, r, ref);
+            // the hit leaf children join the leaf queue, four child slots at a time (capacity: 256 new entries + a
+            // remainder below the flush threshold)
+            queue_leaves4(leaves & 15u, 0, r, base_group, counts, leaf_mask);
+            if (lq_n >= flush_at)
+                flush_leaves();
+            queue_leaves4(leaves >> 4, 4, r, base_group, counts, leaf_mask);
+            if (lq_n >= flush_at)
+                flush_leaves();
             if (lq_n >= flush_at)
                 flush_leaves();
         }
@@ -312,7 +317,7 @@ RT_DEV uint64_t traverse_wide(const SceneView& sv, bool fast, const RayL& ray, c
     WaveLds& L, uint32_t lane)
 {
     uint32_t flush_at = sv.leaf_flush < kWideFlushMax ? sv.leaf_flush : kWideFlushMax;
-    WideWalk<MODE, COUNT> w { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 64u),
+    WideWalk<MODE, COUNT> w { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 128u),
         make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u), 0u,
         flush_at < 1u ? 1u : flush_at };
     uint64_t back = w.run(fast);

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Where a bench frame's time goes, by switching path features on one at a time (throughput setting, moving camera):
+primary rays only -> + shading -> + hard shadows -> + reflections depth 1..4. ms per frame and rays per frame."""
+import importlib, math, os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+import numpy as np
+import torch
+capi = importlib.import_module("computer-graphics-engine_amd.capi")
+abi = importlib.import_module("computer-graphics-engine_amd.abi")
+scenes = importlib.import_module("computer-graphics-engine_amd.scenes")
+sharding = importlib.import_module("computer-graphics-engine_amd.sharding")
+rt = capi.Library()
+data = scenes.get_scene("knot")
+W, H = 1920, 1080
+POSES = 32
+fovy, aspect, look_at, dist_, rot0 = scenes.default_camera_args(W, H)
+cams = [rt.camera(fovy, aspect, look_at, dist_, (rot0[0], rot0[1] + 2 * math.pi * k / POSES, rot0[2])) for k in range(POSES)]
+stream = torch.cuda.current_stream().cuda_stream
+rt.set_option("tile_wlog", 3); rt.set_option("tile_hlog", 3); rt.set_option("leaf_flush", 32)
+variants = [
+    ("primary rays only", dict(enableAccelStructure=1), 0),
+    ("+ shading", dict(enableAccelStructure=1, enableShading=1), 0),
+    ("+ hard shadows", dict(enableAccelStructure=1, enableShading=1, enableHardShadow=1), 0),
+    ("+ reflections depth 1", dict(enableAccelStructure=1, enableShading=1, enableHardShadow=1, enableRecursive=1), 1),
+    ("+ reflections depth 2", dict(enableAccelStructure=1, enableShading=1, enableHardShadow=1, enableRecursive=1), 2),
+    ("+ reflections depth 4 (C3)", dict(enableAccelStructure=1, enableShading=1, enableHardShadow=1, enableRecursive=1), 4),
+]
+bvh = rt.bvh(rt.scene(data), abi.Features.make(enableAccelStructure=1))
+for name, flags, depth in variants:
+    f = abi.Features.make(**flags)
+    p = abi.RenderParams.make(depth=depth)
+    R = sharding.StripRenderer(rt, bvh, cams[0], f, p, W, H, frames_in_flight=2)
+    c = R.count_rays(stream, cam=cams[0])
+    R.prepare(stream, (8,))
+    best = 1e9
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for k in range(0, POSES, 8):
+            R.step(stream, frames=8, cams=cams[k:k + 8])
+            n += 8
+        R.finish()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+    print(f"{name:30s} {best:.4f} ms/frame   rays/frame {c['rays']:9d} (bvh {c['rays'] - c['rays_culled']:9d})  box {c['box_tests']/1e6:6.1f}M tri {c['tri_tests']/1e6:5.1f}M", flush=True)
