@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--exchange-always", action="store_true",
                     help="one GPU: take the strips + RCCL exchange path with a one-rank group (what the N > 1 run "
                          "adds on top of the render: packed strips, all-gather, de-interleave), for measurement")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "allgather"],
+                    help="several GPUs: gather the strips on rank 0 (grouped send / receive, one peer per xGMI link of "
+                         "the root; default) or all-gather them to every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not bracket trace kernels with HIP events during the timed steps")
@@ -157,7 +160,7 @@ def main():
         rt.set_option("tile_hlog", args.tile_log[1])
     renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, rank, world, strip_rows=STRIP_ROWS,
                                       frames_in_flight=args.frames_in_flight, exchange_always=args.exchange_always,
-                                      exchange_batch=args.exchange_batch)
+                                      exchange_batch=args.exchange_batch, exchange=args.exchange)
 
     # ---- camera poses: every frame its own (the reference renders one camera per renderRayTracing call, or one
     #      camera per thread in CLI mode, src/main.cpp:512-531): the default trackball orbits the scene once over
@@ -337,7 +340,7 @@ def main():
                        "tri_tests": per_frame(total["tri_tests"]), "group_tests": per_frame(total.get("group_tests", 0)),
                        "node_fetches": per_frame(total["node_fetches"]),
                        "tri_fetches": per_frame(total["tri_fetches"]), "algorithmic_bytes_per_frame": per_frame(ab["frame"]),
-                       "parallelism": f"strips{STRIP_ROWS}x{world}" + ("+allgather(overlapped" + (f",{renderer.batch}-frames-each)" if renderer.batch > 1 else ")")
+                       "parallelism": f"strips{STRIP_ROWS}x{world}" + (f"+{args.exchange}(overlapped" + (f",{renderer.batch}-frames-each)" if renderer.batch > 1 else ")")
                                                               if renderer.sharded else "")
                        + (f"+{renderer.flight}-launches-in-flight" if renderer.flight > 1 else "")
                        + (f"+{fpl}-frames-per-launch" if fpl > 1 else "")

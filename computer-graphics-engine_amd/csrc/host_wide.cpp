@@ -1,10 +1,10 @@
-// host_wide.cpp — the traversal structure of our own: an 8-wide SAH tree over the scene's triangles.
+// host_wide.cpp — the traversal structure of our own: a 4-wide SAH tree over the scene's triangles.
 //
 // Nothing here has a counterpart in the reference: the reference's tree (median split by depth-cycled axis,
 // 16 levels, src/bounding_volume_hierarchy.cpp:74-147) is built by host_scene.cpp because its LEAVES and the
 // primitive order inside them decide results. Which leaves a ray visits does not depend on the tree above them
 // (rt_wide.h), so the kernels walk this tree instead: binned SAH (16 bins per axis), leaves of up to four
-// triangles, binary tree collapsed to eight children per node (the child with the largest surface area is
+// triangles, binary tree collapsed to four children per node (the child with the largest surface area is
 // opened first). Every slot keeps the triangle's index in the reference's visit order.
 #include "host_scene.h"
 
@@ -48,75 +48,6 @@ struct BNode { // binary build node
     int32_t left = -1, right = -1; // children (internal)
     uint32_t beg = 0, cnt = 0;     // triangle range (leaf)
 };
-
-// a node's children with full-precision bounds, before quantisation
-struct FNode {
-    float lo[kWideWidth][3], hi[kWideWidth][3];
-    uint32_t ref[kWideWidth]; // wide_make_leaf / node index / kWideEmpty
-};
-
-// WideNode from full-precision child bounds: offsets rounded outward (rt_layout.h). The internal children must be
-// consecutive nodes and the leaf children consecutive groups, in child order (build_wide emits them that way).
-bool quantise(const FNode& f, WideNode& q)
-{
-    memset(&q, 0, sizeof(q));
-    for (int a = 0; a < 3; a++) {
-        float lo = FLT_MAX, hi = -FLT_MAX;
-        for (uint32_t k = 0; k < kWideWidth; k++)
-            if (f.ref[k] != kWideEmpty)
-                lo = std::min(lo, f.lo[k][a]), hi = std::max(hi, f.hi[k][a]);
-        if (lo > hi)
-            lo = hi = 0.0f;
-        // the smallest power of two with 255 steps covering the extent
-        const double ext = (double)hi - (double)lo;
-        int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
-        e = std::max(-126, std::min(127, e));
-        while (e < 127 && std::ldexp(255.0, e) < ext)
-            e++;
-        const double scale = std::ldexp(1.0, e);
-        q.origin[a] = lo;
-        q.exps |= (uint32_t)(e + 127) << (8 * a);
-        for (uint32_t k = 0; k < kWideWidth; k++) {
-            uint32_t ql = 0, qh = 0;
-            if (f.ref[k] != kWideEmpty) {
-                ql = (uint32_t)std::max(0.0, std::min(255.0, std::floor(((double)f.lo[k][a] - lo) / scale)));
-                qh = (uint32_t)std::max(0.0, std::min(255.0, std::ceil(((double)f.hi[k][a] - lo) / scale)));
-                // outward: lo + ql * scale <= child lo and lo + qh * scale >= child hi (doubles with few significant bits: exact)
-                while (ql > 0 && (double)lo + ql * scale > (double)f.lo[k][a])
-                    ql--;
-                while (qh < 255 && (double)lo + qh * scale < (double)f.hi[k][a])
-                    qh++;
-                if ((double)lo + qh * scale < (double)f.hi[k][a])
-                    return false; // cannot happen (255 steps cover the extent); never store a box that is too small
-            }
-            q.qlo[a][k >> 2] |= ql << (8 * (k & 3));
-            q.qhi[a][k >> 2] |= qh << (8 * (k & 3));
-        }
-    }
-    bool have_node = false, have_group = false;
-    uint32_t next_node = 0, next_group = 0;
-    for (uint32_t k = 0; k < kWideWidth; k++) {
-        const uint32_t r = f.ref[k];
-        if (r == kWideEmpty)
-            continue;
-        if (wide_is_leaf(r)) {
-            const uint32_t g = wide_leaf_group(r);
-            if (!have_group)
-                q.base_group = g, next_group = g, have_group = true;
-            if (g != next_group++)
-                return false;
-            q.base_group |= 1u << (24 + k);
-            q.counts |= (wide_leaf_count(r) - 1u) << (2 * k);
-        } else {
-            if (!have_node)
-                q.base_node = r, next_node = r, have_node = true;
-            if (r != next_node++)
-                return false;
-            q.exps |= 1u << (24 + k);
-        }
-    }
-    return true;
-}
 
 constexpr int kBins = 16;
 constexpr uint32_t kLeafMax = 4;
@@ -238,7 +169,7 @@ void HostBvh::build_wide()
     if (b.bn[root].left < 0)
         return; // four triangles or fewer: not worth a tree (the root of the reference tree is a leaf too)
 
-    // collapse to eight children per node; nodes in depth-first order, leaf groups in the order they are met
+    // collapse to four children per node; nodes in depth-first order, leaf groups in the order they are met
     struct Item {
         int32_t bnode;
         uint32_t wnode, depth;
@@ -252,10 +183,9 @@ void HostBvh::build_wide()
         const Item it = todo.back();
         todo.pop_back();
         wide_depth = std::max(wide_depth, it.depth);
-        int32_t kids[kWideWidth];
-        kids[0] = b.bn[it.bnode].left, kids[1] = b.bn[it.bnode].right;
+        int32_t kids[4] = { b.bn[it.bnode].left, b.bn[it.bnode].right, -1, -1 };
         int nk = 2;
-        while (nk < (int)kWideWidth) { // open the internal child with the largest surface area
+        while (nk < 4) { // open the internal child with the largest surface area
             int pick = -1;
             double best = -1.0;
             for (int k = 0; k < nk; k++)
@@ -267,14 +197,17 @@ void HostBvh::build_wide()
             kids[pick] = b.bn[open].left;
             kids[nk++] = b.bn[open].right;
         }
-        FNode wn;
+        WideNode wn;
         memset(&wn, 0, sizeof(wn));
-        for (uint32_t k = 0; k < kWideWidth; k++)
+        for (int k = 0; k < 4; k++) {
             wn.ref[k] = kWideEmpty;
+            wn.lox[k] = wn.loy[k] = wn.loz[k] = FLT_MAX; // an empty slot is masked by its reference word
+            wn.hix[k] = wn.hiy[k] = wn.hiz[k] = FLT_MAX;
+        }
         for (int k = 0; k < nk; k++) {
             const BNode& c = b.bn[kids[k]];
-            for (int a = 0; a < 3; a++)
-                wn.lo[k][a] = c.box.lo[a], wn.hi[k][a] = c.box.hi[a];
+            wn.lox[k] = c.box.lo[0], wn.loy[k] = c.box.lo[1], wn.loz[k] = c.box.lo[2];
+            wn.hix[k] = c.box.hi[0], wn.hiy[k] = c.box.hi[1], wn.hiz[k] = c.box.hi[2];
             if (c.left < 0) { // leaf group
                 if (n_groups >= kWideMaxGroups)
                     return;
@@ -298,8 +231,7 @@ void HostBvh::build_wide()
                 todo.push_back({ kids[k], wn.ref[k], it.depth + 1 });
             }
         }
-        if (!quantise(wn, wide_nodes[it.wnode]))
-            return;
+        wide_nodes[it.wnode] = wn;
     }
     wide_ok = true;
 }

@@ -101,37 +101,26 @@ RT_LAYOUT_FN uint32_t cw_make_big(uint32_t count) { return 0x80000000u | (count 
 // ---- The traversal structure of our own (rt_wide.h) ------------------------------------------------------
 // The reference's visit set does not depend on the tree ABOVE its leaves: its box test is monotone under box
 // inclusion (rt_wide.h has the argument and its three exceptions), so a leaf is visited exactly when its OWN
-// box passes the exact test. The kernels therefore walk a 8-wide SAH tree built over the TRIANGLES (not the
+// box passes the exact test. The kernels therefore walk a 4-wide SAH tree built over the TRIANGLES (not the
 // reference's median-split tree) with cheap conservative box tests, run the reference's exact triangle test
 // on the leaves' triangles, and check a would-be candidate against the exact test of the reference leaf it
 // lives in (the winner only: rt_wide.h). Tie ranks (the index in the reference's visit order) ride along per slot.
 //
-// WideNode: EIGHT children in 76 bytes (one 128-byte line per node). The traversal is bound by the number of
-// dependent memory round trips per ray (profiles/r02_notes.md), so a node holds as many children as one fetch can
-// pay for; and because the kernel's box test is conservative by construction, the children's bounds are stored as
-// 8-bit offsets inside the node's own box, rounded OUTWARD:
-//     child k, axis a:  lo = origin[a] + qlo[a].byte[k] * 2^(exp[a] - 127),  hi = origin[a] + qhi[a].byte[k] * 2^(exp[a] - 127)
-// (origin = lower corner of the union of the children; 2^(exp - 127) * 255 >= its extent). A quantised box contains
-// the exact one, so no candidate is lost; it is at most 1/255 of the node's extent wider per plane.
-// Children: the internal children of a node are consecutive WideNodes starting at base_node, its leaf groups
-// consecutive groups starting at base_group — child k is the (number of same-kind children before k)-th of its
-// kind; group g holds slots [4g, 4g + count) of `wide_leaf` / `wide_index`.
+// WideNode: four children, SoA so that one child is one lane of a float4. 128 bytes, 128-byte aligned.
+// Child reference word:
+//   0xffffffff          empty slot
+//   bit 31 set          leaf group: bits 30:29 = triangles - 1 (1..4), bits 23:0 = group index;
+//                       group g holds slots [4g, 4g + count) of `wide_leaf` / `wide_index`
+//   otherwise           internal node: index into the WideNode array (< 2^26)
 struct alignas(128) WideNode {
-    float origin[3];
-    uint32_t exps;          // biased exponents of the axes' scales: x bits 7:0, y 15:8, z 23:16; bits 31:24: mask of internal children
-    uint32_t qlo[3][2];     // per axis: the children's lower offsets, child k in byte k & 3 of word k >> 2
-    uint32_t qhi[3][2];
-    uint32_t base_node;     // first internal child (< 2^26)
-    uint32_t base_group;    // bits 23:0 first leaf group; bits 31:24: mask of leaf children
-    uint32_t counts;        // child k's triangles - 1 in bits 2k+1:2k (leaf children)
-    uint32_t pad[13];
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    uint32_t ref[4];
+    uint32_t pad[4];
 };
-static_assert(sizeof(WideNode) == 128, "WideNode must be one 128-byte line");
-constexpr uint32_t kWideWidth = 8;
+static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
 constexpr uint32_t kWideEmpty = 0xffffffffu;
 constexpr uint32_t kWideMaxNodes = 1u << 26, kWideMaxGroups = 1u << 24;
-// host-side child reference while a node is assembled (host_wide.cpp): 0xffffffff empty, bit 31 leaf group
-// (bits 30:29 triangles - 1, bits 23:0 group), else internal node index
 RT_LAYOUT_FN bool wide_is_leaf(uint32_t ref) { return (ref >> 31) != 0u; }
 RT_LAYOUT_FN uint32_t wide_leaf_group(uint32_t ref) { return ref & 0xffffffu; }
 RT_LAYOUT_FN uint32_t wide_leaf_count(uint32_t ref) { return ((ref >> 29) & 3u) + 1u; }

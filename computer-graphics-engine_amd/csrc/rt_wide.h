@@ -1,4 +1,4 @@
-// rt_wide.h — the wide engine: traversal of our own 8-wide SAH tree (rt_layout.h WideNode, host_wide.cpp)
+// rt_wide.h — the wide engine: traversal of our own 4-wide SAH tree (rt_layout.h WideNode, host_wide.cpp)
 // that returns the bits of the reference's traversal of ITS tree.
 //
 // Why a different tree may be walked. For a ray whose three direction components are non-zero, finite and of
@@ -13,11 +13,10 @@
 // is never tested (bvh.cpp:313). So for such a ray
 //     the reference visits a leaf  <=>  T(leaf's own box), unless that test passes with tout == 0,
 // whatever the tree above the leaves looks like. The wide engine therefore
-//   * walks the wide tree with a CONSERVATIVE box test: the children's bounds are 8-bit offsets inside the node's
-//     box, rounded outward (rt_layout.h WideNode), one conversion + one FMA per slab plane, the interval widened
-//     by the pruning slack (rt_device.h "Pruning": a candidate's point lies within rho = 2^-16 x scene scale of
-//     its triangle, hence of every box around it; the roundings of the FMA form stay below 1/32 of the slack),
-//     pruned by min(initial ray.t, best t so far) like the exact engine;
+//   * walks the wide tree with a CONSERVATIVE box test: one FMA per slab plane, the interval widened by the
+//     pruning slack (rt_device.h "Pruning": a candidate's point lies within rho = 2^-16 x scene scale of its
+//     triangle, hence of every box around it; the FMA form adds at most 2^-22 x scale x |1/d| of rounding,
+//     1/64 of the slack), pruned by min(initial ray.t, best t so far) like the exact engine;
 //   * runs the reference's exact triangle test (Appendix A.1/A.2) on the triangles of the leaf groups reached;
 //   * keeps, per ray, the smallest key among ALL triangles that pass that test (wide_index gives a slot's index in
 //     the reference's visit order, so ties resolve as there) and prunes with it;
@@ -98,27 +97,34 @@ struct WideWalk {
         lq_n = 0;
     }
 
-    // Hit leaf children k0 .. k0 + 3 of every lane (`four`: their hit bits) appended to the leaf queue: one prefix sum
-    // over the lanes' counts (three ballots: the bits of a count 0..4) instead of one ballot + prefix per child.
-    // Child k is the (leaf children before k)-th group from base_group; entry: group | (triangles - 1) << 24 | ray << 26.
-    RT_DEV void queue_leaves4(uint32_t four, int k0, uint32_t r, uint32_t base_group, uint32_t counts, uint32_t leaf_mask)
+    // the lanes' hit leaf children (up to four each) appended to the leaf queue: one prefix sum over the lanes'
+    // counts (three ballots: the bits of a count 0..4) instead of one ballot + prefix per child
+    RT_DEV void queue_leaves4(const bool lf[4], uint32_t r, const uint32_t ref[4])
     {
-        const uint32_t c = (uint32_t)__builtin_popcount(four);
+        const uint32_t c = (uint32_t)lf[0] + (uint32_t)lf[1] + (uint32_t)lf[2] + (uint32_t)lf[3];
         const uint64_t any = ballot(c != 0u);
         if (any == 0)
             return;
         const uint64_t b0 = ballot((c & 1u) != 0u), b1 = ballot((c & 2u) != 0u), b2 = ballot((c & 4u) != 0u);
         uint32_t o = lq_n + prefix_count(b0) + 2u * prefix_count(b1) + 4u * prefix_count(b2);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if ((four >> j) & 1u) {
-                const int k = k0 + j;
-                const uint32_t group = (base_group & 0xffffffu) + (uint32_t)__builtin_popcount(leaf_mask & ((1u << k) - 1u));
-                L.wlq[o] = group | (((counts >> (2 * k)) & 3u) << 24) | (r << 26);
+        for (int k = 0; k < 4; k++) {
+            if (lf[k]) { // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
+                L.wlq[o] = (ref[k] & 0xffffffu) | (((ref[k] >> 29) & 3u) << 24) | (r << 26);
                 o++;
             }
         }
         lq_n += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) + 4u * (uint32_t)__builtin_popcountll(b2);
+    }
+
+    RT_DEV void queue_leaf(bool want, uint32_t r, uint32_t ref)
+    {
+        const uint64_t m = ballot(want);
+        if (m) {
+            if (want) // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
+                L.wlq[lq_n + prefix_count(m)] = (ref & 0xffffffu) | (((ref >> 29) & 3u) << 24) | (r << 26);
+            lq_n += (uint32_t)__builtin_popcountll(m);
+        }
     }
 
     // ---- node phase: private deques + work stealing, as in the exact engine -------------------------------
@@ -179,8 +185,8 @@ struct WideWalk {
                     wave_lds_fence();
                 }
             }
-            uint32_t leaves = 0u;       // mask of this lane's hit leaf children
-            uint32_t base_group = 0u, counts = 0u, leaf_mask = 0u;
+            bool lf[4] = { false, false, false, false };
+            uint32_t ref[4] = { 0u, 0u, 0u, 0u };
             uint32_t r = 0;
             if (have) {
                 have = false;
@@ -193,92 +199,77 @@ struct WideWalk {
                 const bool skip = (any & (bk != kNoHit)) | (!any & (e_lb > lim));
                 if (!skip) {
                     const uint32_t noff = (e >> 6) * 128u;
-                    const float4 w0 = buf_load16(nodes, noff), w1 = buf_load16(nodes, noff + 16u), w2 = buf_load16(nodes, noff + 32u);
-                    const float4 w3 = buf_load16(nodes, noff + 48u), w4 = buf_load16(nodes, noff + 64u);
+                    const float4 lox = buf_load16(nodes, noff), loy = buf_load16(nodes, noff + 16u);
+                    const float4 loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
+                    const float4 hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
+                    const float4 rf = buf_load16(nodes, noff + 96u);
                     asm volatile("" ::"v"(touched)); // the touch is over by now (loads return in order)
-                    // Child plane: b = origin + q * 2^(exp - 127); t = b * (1/d) - o * (1/d) = q * (scale / d) + (origin - o) / d:
-                    // one conversion and one FMA per plane. s covers the roundings (each below 2^-21 x scene scale x |1/d|,
-                    // 1/32 of the slack) and the box growth rho.
+                    ref[0] = __float_as_uint(rf.x), ref[1] = __float_as_uint(rf.y);
+                    ref[2] = __float_as_uint(rf.z), ref[3] = __float_as_uint(rf.w);
+                    // t = b * (1/d) - o * (1/d): one FMA per slab plane; s covers its rounding and the box growth rho
                     const float s = rc.w * 1.0625f;
-                    const uint32_t ex = __float_as_uint(w0.w);
-                    const float sx = __uint_as_float((ex & 0xffu) << 23) * rc.x, sy = __uint_as_float(((ex >> 8) & 0xffu) << 23) * rc.y;
-                    const float sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rc.z;
-                    const float ox = (w0.x - ra.x) * rc.x, oy = (w0.y - ra.y) * rc.y, oz = (w0.z - ra.z) * rc.z;
+                    const float ox = ra.x * rc.x, oy = ra.y * rc.y, oz = ra.z * rc.z;
                     const float s2 = s + s, ms = -s, lims = lim + s;
-                    // qlo x: w1.x w1.y, y: w1.z w1.w, z: w2.x w2.y; qhi x: w2.z w2.w, y: w3.x w3.y, z: w3.z w3.w
-                    const uint32_t qx0[2] = { __float_as_uint(w1.x), __float_as_uint(w1.y) }, qy0[2] = { __float_as_uint(w1.z), __float_as_uint(w1.w) };
-                    const uint32_t qz0[2] = { __float_as_uint(w2.x), __float_as_uint(w2.y) }, qx1[2] = { __float_as_uint(w2.z), __float_as_uint(w2.w) };
-                    const uint32_t qy1[2] = { __float_as_uint(w3.x), __float_as_uint(w3.y) }, qz1[2] = { __float_as_uint(w3.z), __float_as_uint(w3.w) };
-                    const uint32_t base_node = __float_as_uint(w4.x), int_mask = ex >> 24;
-                    base_group = __float_as_uint(w4.y), counts = __float_as_uint(w4.z);
-                    leaf_mask = base_group >> 24;
-                    auto byte_f = [](uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }; // v_cvt_f32_ubyteK
-                    uint32_t hits = 0u; // children whose (widened) box the ray may pass within [0, lim]
-                    float lbk[8];
+                    const float bx0[4] = { lox.x, lox.y, lox.z, lox.w }, bx1[4] = { hix.x, hix.y, hix.z, hix.w };
+                    const float by0[4] = { loy.x, loy.y, loy.z, loy.w }, by1[4] = { hiy.x, hiy.y, hiy.z, hiy.w };
+                    const float bz0[4] = { loz.x, loz.y, loz.z, loz.w }, bz1[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+                    bool in[4];
+                    float lbk[4];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int w = k >> 2, b = k & 3;
-                        const float tx0 = __builtin_fmaf(byte_f(qx0[w], b), sx, ox), tx1 = __builtin_fmaf(byte_f(qx1[w], b), sx, ox);
-                        const float ty0 = __builtin_fmaf(byte_f(qy0[w], b), sy, oy), ty1 = __builtin_fmaf(byte_f(qy1[w], b), sy, oy);
-                        const float tz0 = __builtin_fmaf(byte_f(qz0[w], b), sz, oz), tz1 = __builtin_fmaf(byte_f(qz1[w], b), sz, oz);
+                    for (int k = 0; k < 4; k++) {
+                        const float tx0 = __builtin_fmaf(bx0[k], rc.x, -ox), tx1 = __builtin_fmaf(bx1[k], rc.x, -ox);
+                        const float ty0 = __builtin_fmaf(by0[k], rc.y, -oy), ty1 = __builtin_fmaf(by1[k], rc.y, -oy);
+                        const float tz0 = __builtin_fmaf(bz0[k], rc.z, -oz), tz1 = __builtin_fmaf(bz1[k], rc.z, -oz);
                         const float tin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
                         const float tout = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-                        // positive comparisons: a NaN — impossible for an all_ok ray and a finite box — would drop the
-                        // child, never a real one; empty children are in neither kind mask
-                        const bool hit = (tin <= tout + s2) & (tout >= ms) & (tin <= lims);
-                        hits |= hit ? (1u << k) : 0u;
+                        // may the ray pass within the slack of the box at a distance in [0, lim]? (positive comparisons:
+                        // a NaN — impossible for an all_ok ray and a finite box — would drop the child, never a real one)
+                        const bool hit = (tin <= tout + s2) & (tout >= ms) & (tin <= lims) & (ref[k] != kWideEmpty);
                         lbk[k] = tin - s;
+                        lf[k] = hit & wide_is_leaf(ref[k]);
+                        in[k] = hit & !wide_is_leaf(ref[k]);
                     }
-                    leaves = hits & leaf_mask;
-                    uint32_t inner = hits & int_mask;
                     if (COUNT) {
                         lc.node_fetch++;
-                        lc.box += (uint32_t)__builtin_popcount(int_mask | leaf_mask);
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            lc.box += ref[k] != kWideEmpty ? 1u : 0u;
                     }
                     // the nearest internal child becomes the current entry, the others are put aside
                     int near = -1;
                     float near_lb = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const bool better = ((inner >> k) & 1u) & ((near < 0) | (lbk[k] < near_lb));
+                    for (int k = 0; k < 4; k++) {
+                        const bool better = in[k] & ((near < 0) | (lbk[k] < near_lb));
                         near = better ? k : near;
                         near_lb = better ? lbk[k] : near_lb;
                     }
-                    // room for the (up to seven) others? otherwise the exact engine traces this ray — its entries here
-                    // are dropped, the result is discarded anyway
-                    const uint32_t n_push = (uint32_t)__builtin_popcount(inner) - (near >= 0 ? 1u : 0u);
-                    if (sp + n_push > kWideStack) {
+                    // room for the (up to three) others? otherwise the exact engine traces this ray — its entries here are
+                    // dropped, the result is discarded anyway
+                    if (sp + 3u > kWideStack && ((int)in[0] + (int)in[1] + (int)in[2] + (int)in[3] - (near >= 0 ? 1 : 0)) + (int)sp > (int)kWideStack) {
                         flag_fallback(r);
                         near = -1;
-                        inner = 0u;
+                        in[0] = in[1] = in[2] = in[3] = false;
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        if (((inner >> k) & 1u) & (k != near)) {
-                            const uint32_t node = base_node + (uint32_t)__builtin_popcount(int_mask & ((1u << k) - 1u));
-                            L.wstack[sp][lane] = (node << 6) | r;
+                    for (int k = 0; k < 4; k++) {
+                        if (in[k] & (k != near)) {
+                            L.wstack[sp][lane] = (ref[k] << 6) | r;
                             L.wstack_lb[sp][lane] = (uint16_t)lb_to_u16(lbk[k]);
                             sp++;
                         }
                     }
                     if (near >= 0) {
-                        const uint32_t nnode = base_node + (uint32_t)__builtin_popcount(int_mask & ((1u << near) - 1u));
-                        e = (nnode << 6) | r;
+                        const uint32_t nref = near == 0 ? ref[0] : (near == 1 ? ref[1] : (near == 2 ? ref[2] : ref[3]));
+                        e = (nref << 6) | r;
                         e_lb = near_lb;
                         have = true;
                         if (prefetch) // bring the next node's line towards this CU while the step's bookkeeping runs
-                            touched = __builtin_amdgcn_raw_buffer_load_b32(nodes, nnode * 128u, 0, 0);
+                            touched = __builtin_amdgcn_raw_buffer_load_b32(nodes, nref * 128u, 0, 0);
                     }
                 }
             }
-            // the hit leaf children join the leaf queue, four child slots at a time (capacity: 256 new entries + a
-            // remainder below the flush threshold)
-            queue_leaves4(leaves & 15u, 0, r, base_group, counts, leaf_mask);
-            if (lq_n >= flush_at)
-                flush_leaves();
-            queue_leaves4(leaves >> 4, 4, r, base_group, counts, leaf_mask);
-            if (lq_n >= flush_at)
-                flush_leaves();
+            queue_leaves4(lf, r, ref);
             if (lq_n >= flush_at)
                 flush_leaves();
         }

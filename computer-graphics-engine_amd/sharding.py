@@ -50,16 +50,47 @@ def deinterleave_numpy(gathered: np.ndarray, height: int, strip_rows: int) -> np
     return frame
 
 
-def gather_strips(gathered, local):
-    """The ONE exchange step of a frame: every rank's packed strips → every rank.
-    RCCL (backend nccl) takes the flat all-gather; gloo (CPU tests) has no
-    _allgather_base, so it gets the list form over views of the same buffer."""
+def gather_strips(gathered, local, root=None):
+    """The ONE exchange step of a frame (or of a batch of frames).
+    root = None: every rank's packed strips → every rank (all-gather; every rank ends up with the frame).
+    root = r:    → rank r only, as one grouped send / receive per peer (ncclGroupStart … ncclSend / ncclRecv …
+                 ncclGroupEnd through torch's batch_isend_irecv): each of the root's xGMI links carries exactly one
+                 peer's buffer, W*H*12/world bytes each, instead of the (world-1)/world of the whole frame that a
+                 ring all-gather pushes through EVERY link — at the render rates of this path the frame gather is
+                 what limits scaling, so the bench uses this form.
+    RCCL (backend nccl) takes the flat calls; gloo (CPU tests, one-GPU rehearsals) gets list / staged forms."""
+    import torch
     import torch.distributed as dist
 
-    if dist.get_backend() == "gloo":
-        dist.all_gather(list(gathered.unbind(0)), local)
+    gloo = dist.get_backend() == "gloo"
+    if root is None:
+        if gloo:
+            dist.all_gather(list(gathered.unbind(0)), local)
+        else:
+            dist.all_gather_into_tensor(gathered, local)
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank == root:
+        gathered[root].copy_(local)
+    if world == 1:
+        return
+    if gloo:  # blocking point-to-point calls, staged through host memory for device tensors
+        if rank == root:
+            for r in range(world):
+                if r != root:
+                    buf = torch.empty(local.shape, dtype=local.dtype) if local.is_cuda else gathered[r]
+                    dist.recv(buf, src=r)
+                    if local.is_cuda:
+                        gathered[r].copy_(buf)
+        else:
+            dist.send(local.cpu() if local.is_cuda else local, dst=root)
+        return
+    if rank == root:
+        ops = [dist.P2POp(dist.irecv, gathered[r], r) for r in range(world) if r != root]
     else:
-        dist.all_gather_into_tensor(gathered, local)
+        ops = [dist.P2POp(dist.isend, local, root)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()  # orders the current stream after the transfer; the host does not wait
 
 
 def new_streams(n: int, high_priority: bool = False):
@@ -100,7 +131,7 @@ class StripRenderer:
 
     def __init__(self, rt, bvh, cam, features, params, width, height, rank=0, world=1, strip_rows=8,
                  overlap=True, frames_in_flight=1, exchange_always=False,
-                 exchange_batch=1):
+                 exchange_batch=1, exchange="allgather"):
         """frames_in_flight > 1: successive frames go to alternating HIP streams, each with its own
         buffers and library scratch, so the tail of frame k — a few long path trees on an otherwise
         idle chip — overlaps the start of the next frames (with several ranks: the rank's strips of
@@ -113,7 +144,8 @@ class StripRenderer:
         (one communicator, one order), so they are made fewer. Every frame is still rendered,
         exchanged and assembled; finish() flushes a partial batch.
         exchange_always: take the strips + exchange path with ONE rank too (the all-gather of a
-        one-rank group) — how the GPU tests drive the RCCL branch on a one-GPU box."""
+        one-rank group) — how the GPU tests drive the RCCL branch on a one-GPU box.
+        exchange: "allgather" — every rank assembles the frame; "gather" — rank 0 only (gather_strips)."""
         import torch
 
         self.rt, self.bvh, self.cam, self.f, self.p = rt, bvh, cam, features, params
@@ -122,6 +154,7 @@ class StripRenderer:
         self.frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
         self.counters = torch.zeros(16, dtype=torch.int64, device="cuda")
         self.sharded = world > 1 or exchange_always
+        self.root = 0 if exchange == "gather" else None   # who assembles the frame (None: every rank)
         self.overlap = overlap and self.sharded
         self.k = 0         # frames stepped (several ranks: position in the exchange batches)
         self.launches = 0  # launches issued: launch n goes to render stream n % flight
@@ -235,11 +268,12 @@ class StripRenderer:
             self._log(0, 1)
             self.rt.render_device(self.bvh, cams[0], self.f_strips, self.p, self.W, self.H, self.local[0].data_ptr(),
                                   rows=self.rows, packed=True, stream=stream)
-            gather_strips(self.gathered[0], self.local[0])
-            self.rt.deinterleave_strips(self.gathered[0].data_ptr(), self.frame.data_ptr(), self.W, self.H,
-                                        self.strip_rows, self.world, stream=stream)
-            if self.bloom:
-                self.rt.bloom_device(self.frame.data_ptr(), self.W, self.H, self.p, stream=stream)
+            gather_strips(self.gathered[0], self.local[0], self.root)
+            if self.root is None or self.rank == self.root:
+                self.rt.deinterleave_strips(self.gathered[0].data_ptr(), self.frame.data_ptr(), self.W, self.H,
+                                            self.strip_rows, self.world, stream=stream)
+                if self.bloom:
+                    self.rt.bloom_device(self.frame.data_ptr(), self.W, self.H, self.p, stream=stream)
             return
         # frames in flight: frame k renders on stream k % flight, so the tail of one rank's share (a
         # few long path trees) overlaps the shares of the next frames; the exchanges follow in frame
@@ -279,13 +313,14 @@ class StripRenderer:
         with torch.cuda.stream(self.comm_stream):
             for e in self.rendered[i][:n]:
                 self.comm_stream.wait_event(e)
-            gather_strips(self.gathered[i], self.local[i])
+            gather_strips(self.gathered[i], self.local[i], self.root)
             raw = self.comm_stream.cuda_stream
-            self.rt.deinterleave_frames(self.gathered[i].data_ptr(), self.out[i].data_ptr(), self.W, self.H,
-                                        self.strip_rows, self.world, n, self.batch, stream=raw)
-            if self.bloom:
-                for b in range(n):
-                    self.rt.bloom_device(self.out[i][b].data_ptr(), self.W, self.H, self.p, stream=raw)
+            if self.root is None or self.rank == self.root:
+                self.rt.deinterleave_frames(self.gathered[i].data_ptr(), self.out[i].data_ptr(), self.W, self.H,
+                                            self.strip_rows, self.world, n, self.batch, stream=raw)
+                if self.bloom:
+                    for b in range(n):
+                        self.rt.bloom_device(self.out[i][b].data_ptr(), self.W, self.H, self.p, stream=raw)
             self.consumed[i].record(self.comm_stream)
         self.used[i] = True
         self.frame = self.out[i][n - 1]

@@ -28,7 +28,7 @@ def pattern_row(y, width):
     return np.stack([x + 1000 * y, x * 0 + y, x * 0.5 - y], axis=-1).astype(np.float32)
 
 
-def _worker(rank, world, height, width, port, out_dir):
+def _worker(rank, world, height, width, port, out_dir, root=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,7 +38,7 @@ def _worker(rank, world, height, width, port, out_dir):
     for i, y in enumerate(rows):               # "render" this rank's strips, packed
         local[i] = torch.from_numpy(pattern_row(int(y), width))
     gathered = torch.zeros((world, rmax, width, 3), dtype=torch.float32)
-    sharding.gather_strips(gathered, local)
+    sharding.gather_strips(gathered, local, root)
     frame = sharding.deinterleave_numpy(gathered.numpy(), height, 8)
     np.save(os.path.join(out_dir, f"frame_{rank}.npy"), frame)
     dist.destroy_process_group()
@@ -53,3 +53,18 @@ def test_two_rank_gather_reassembles_the_flipped_frame(tmp_path, height):
     for r in range(world):
         got = np.load(tmp_path / f"frame_{r}.npy")
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 0), (3, 2)])
+def test_gather_to_root_reassembles_the_frame_on_the_root_only(tmp_path, world, root):
+    """gather_strips(root=r): one send per peer, only the root holds the strips (what bench.py --gpus N uses;
+    over RCCL the same calls are one grouped ncclSend / ncclRecv per peer)."""
+    height, width = 76, 16
+    port = 29850 + (os.getpid() % 100) + 10 * world + root
+    mp.spawn(_worker, args=(world, height, width, port, str(tmp_path), root), nprocs=world, join=True)
+    want = np.stack([pattern_row(height - 1 - fy, width) for fy in range(height)])
+    assert np.array_equal(np.load(tmp_path / f"frame_{root}.npy"), want)
+    for r in range(world):
+        if r != root:  # a peer keeps only its own strips (gathered[r] stays zero elsewhere)
+            got = np.load(tmp_path / f"frame_{r}.npy")
+            assert not np.array_equal(got, want)

@@ -90,29 +90,19 @@ static void trace_wide(const HostBvh& b, const Ray& r, bool any_hit, double tmax
         have = false;
         st.steps++;
         const WideNode& n = b.wide_nodes[cur.node];
-        E kids[8];
+        E kids[4];
         int nk = 0;
-        const uint32_t int_mask = n.exps >> 24, leaf_mask = n.base_group >> 24;
-        uint32_t n_int = 0, n_leaf = 0;
-        for (uint32_t k = 0; k < kWideWidth; k++) {
-            const bool is_int = (int_mask >> k) & 1u, is_leaf = (leaf_mask >> k) & 1u;
-            if (!is_int && !is_leaf)
+        for (int k = 0; k < 4; k++) {
+            if (n.ref[k] == kWideEmpty)
                 continue;
-            const uint32_t rank_i = n_int, rank_l = n_leaf;
-            n_int += is_int, n_leaf += is_leaf;
             st.child_tests++;
-            float lo[3], hi[3]; // the quantised bounds the kernel sees (rt_layout.h WideNode)
-            for (int a = 0; a < 3; a++) {
-                const float scale = std::ldexp(1.0f, (int)((n.exps >> (8 * a)) & 0xffu) - 127);
-                lo[a] = n.origin[a] + (float)((n.qlo[a][k >> 2] >> (8 * (k & 3))) & 0xffu) * scale;
-                hi[a] = n.origin[a] + (float)((n.qhi[a][k >> 2] >> (8 * (k & 3))) & 0xffu) * scale;
-            }
+            const float lo[3] = { n.lox[k], n.loy[k], n.loz[k] }, hi[3] = { n.hix[k], n.hiy[k], n.hiz[k] };
             double tin;
             if (!slab(lo, hi, r, best, tin))
                 continue;
-            if (is_leaf) {
+            if (wide_is_leaf(n.ref[k])) {
                 st.leaf_visits++;
-                const uint32_t g = (n.base_group & 0xffffffu) + rank_l, c = ((n.counts >> (2 * k)) & 3u) + 1u;
+                const uint32_t g = wide_leaf_group(n.ref[k]), c = wide_leaf_count(n.ref[k]);
                 for (uint32_t j = 0; j < c; j++) {
                     st.tri_tests++;
                     double t;
@@ -120,7 +110,7 @@ static void trace_wide(const HostBvh& b, const Ray& r, bool any_hit, double tmax
                         best = t, found = true;
                 }
             } else {
-                kids[nk++] = E { n.base_node + rank_i, tin };
+                kids[nk++] = E { n.ref[k], tin };
             }
         }
         if (any_hit && found)
