@@ -1170,10 +1170,11 @@ int rt_render_frames(const rt_bvh* cbvh, const rt_camera* cameras, int32_t n_fra
     std::lock_guard<std::mutex> g(g_host_call_mu);
     Scratch& sc = bvh->scratch_for(nullptr);
     const size_t frame_floats = (size_t)width * height * 3;
-    // groups of up to kMaxFramesPerLaunch frames: one launch each (or one launch per frame when the frames
+    // groups of up to 8 frames: one launch each (or one launch per frame when the frames
     // cannot share one, rt_render_device_frames), one copy back per group
-    for (int32_t k0 = 0; k0 < n_frames; k0 += rt::kMaxFramesPerLaunch) {
-        const int32_t n = std::min<int32_t>(rt::kMaxFramesPerLaunch, n_frames - k0);
+    constexpr int32_t kGroup = 8; // whole frames: eight fill the chip, and the staging buffer stays at 8 frames
+    for (int32_t k0 = 0; k0 < n_frames; k0 += kGroup) {
+        const int32_t n = std::min<int32_t>(kGroup, n_frames - k0);
         HIP_TRY(sc.frame.reserve(frame_floats * (size_t)n));
         const int rc = rt_render_device_frames(cbvh, cameras + k0, n, features, params, width, height, nullptr, height, 0,
             sc.frame.p, 0, nullptr);

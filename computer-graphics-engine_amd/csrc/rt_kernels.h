@@ -46,7 +46,7 @@ struct CameraArgs {
     // never straddles two frames); frame f's origin / rotation are poses[f]. n_frames <= 1: a plain launch.
     int32_t n_frames, frame_rows;
 };
-constexpr int32_t kMaxFramesPerLaunch = 8;
+constexpr int32_t kMaxFramesPerLaunch = 32; // a rank's small share of a frame at 8 ranks: 32 shares = 4 frames' worth of work per launch
 struct CameraPose {
     float origin[3], quat[4];
 };

@@ -348,6 +348,8 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                 rs.d = mk(__shfl(ray.d.x, src, 64), __shfl(ray.d.y, src, 64), __shfl(ray.d.z, src, 64));
                 const float ts = __shfl(t, src, 64);
                 const uint32_t pix_s = (uint32_t)__shfl((int)pixel, src, 64);
+                const bool try_known = use_bvh && prune && sv.wide_ok != 0u;
+                int32_t known = -1; // what blocked this lane's previous sample is tried first (wide_known_blocker)
                 for (int32_t s0 = 0; s0 < nsamp; s0 += (int32_t)batch) {
                     const int32_t s_mine = s0 + (int32_t)kk;
                     const bool mine = kk < batch && s_mine < nsamp;
@@ -356,8 +358,15 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                     const RayL sray = shadow_ray(rs, ts, lp);
                     float st = 1.0f;
                     int32_t spos;
-                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, mine, sray, st, spos, lc, wl);
-                    const int blocked = spos >= 0 ? 1 : 0;
+                    bool need = mine, by_known = false;
+                    if (try_known && ballot(mine && known >= 0)) {
+                        if (mine && known >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)known, lc))
+                            need = false, by_known = true;
+                    }
+                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
+                    if (spos >= 0)
+                        known = spos;
+                    const int blocked = (spos >= 0 || by_known) ? 1 : 0;
                     for (uint32_t j = 0; j < batch && s0 + (int32_t)j < nsamp; j++) {
                         const float visibility = __shfl(blocked, (int)((q_mine + j * n_hit) & 63u), 64) ? 0.0f : 1.0f;
                         V3 lpos, lcol;
@@ -372,6 +381,9 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                 }
                 s_begin = nsamp;
             }
+            // area lights: what blocked a pixel's previous sample is tried first for the next one (wide_known_blocker)
+            const bool try_blocker = !LEAN && !GENERAL && !is_point && use_bvh && prune && sv.wide_ok != 0u;
+            int32_t last_blocker = -1;
             for (int32_t s = s_begin; s < nsamp; s++) {
                 V3 lpos, lcol;
                 light_sample(L, kind, a, pixel, level, li, s, lpos, lcol);
@@ -382,6 +394,13 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                     int32_t spos;
                     if (COUNT && hit)
                         rc.shadow++;
+                    bool need = hit;
+                    if (try_blocker && ballot(hit && last_blocker >= 0)) {
+                        if (hit && last_blocker >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)last_blocker, lc)) {
+                            visibility = 0.0f;
+                            need = false;
+                        }
+                    }
                     if (!GENERAL && mg && mg->enabled && !mg->done) {
                         const uint32_t lane = lane_id();
                         const bool upper = lane >= 32u;
@@ -405,9 +424,11 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                         if (spos >= 0)
                             visibility = 0.0f;
                     } else if (!GENERAL || !(flags & F_TRANSPARENCY)) {
-                        traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
-                        if (spos >= 0)
+                        traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
+                        if (spos >= 0) {
                             visibility = 0.0f;
+                            last_blocker = spos;
+                        }
                     } else { // light.cpp:66-69: the CLOSEST blocker's material.transparency
                         traverse<Q_CLOSEST, COUNT>(sv, use_bvh, prune, hit, sray, st, spos, lc, wl);
                         if (spos >= 0)

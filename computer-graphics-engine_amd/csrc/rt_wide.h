@@ -299,6 +299,28 @@ RT_DEV bool wide_winner_stands(const SceneView& sv, const RayL& ray, const RayIn
     return (tin < 0.0f ? tout > 0.0f : tin <= tout) && tout != 0.0f;
 }
 
+// Does triangle `pos` (index in the reference's visit order) block this shadow ray, i.e. is it one of the
+// reference's candidates with 0 <= t <= 1? Exactly that when it answers true: the reference's triangle test passes
+// (Appendix A.1/A.2, the precomputed plane and edges of PrimRecord) AND the reference visits the triangle's leaf
+// (exact box test of its reference leaf, header comment) — then BvhInterface::intersect reports a hit whatever else
+// lies along the ray. false = "not known": the caller traverses. Used to try the previous sample's blocker first
+// for the many shadow rays of an area light (light.cpp:139-157); any-hit results do not depend on the order in which
+// candidates are looked at.
+template <bool COUNT>
+RT_DEV bool wide_known_blocker(const SceneView& sv, const RayL& ray, uint32_t pos, LaneCounters& lc)
+{
+    const RayInv inv = make_ray_inv(ray, sv.extent);
+    if (!inv.all_ok())
+        return false;
+    const PrimRecord rec = sv.prims[pos];
+    float tt;
+    if (COUNT)
+        lc.tri++;
+    if (!tri_candidate(rec, ray, 1.0f, tt))
+        return false;
+    return wide_winner_stands<COUNT>(sv, ray, inv, make_key(tt, pos, false), lc);
+}
+
 // Ray slots with `fast` set (all_ok rays: the caller checks) are traced through the wide tree (closest hit /
 // any hit per slot as MODE says); on return L.best holds their keys, and the returned mask names the slots whose
 // result must be discarded and traced by the exact engine instead. `ray` / `inv`: the lane's own ray (slot = lane).

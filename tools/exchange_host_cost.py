@@ -28,9 +28,9 @@ tw, th = [int(x) for x in os.environ.get("TILE", "1,3").split(",")]
 rt.set_option("tile_wlog", tw); rt.set_option("tile_hlog", th)
 skip = os.environ.get("SKIP", "")
 if "gather" in skip:
-    sharding.gather_strips = lambda g, l: None
+    sharding.gather_strips = lambda g, l, root=None: None
 if "copy" in skip:      # a plain device copy in place of the one-rank all-gather
-    sharding.gather_strips = lambda g, l: g[0].copy_(l)
+    sharding.gather_strips = lambda g, l, root=None: g[0].copy_(l)
 if "deint" in skip:
     rt.deinterleave_strips = lambda *a, **k: None
 for flight in [int(x) for x in os.environ.get("FLIGHTS", "1,2,8,16").split(",")]:
