@@ -6,24 +6,37 @@ traversed) at 1920x1080; frame ms; 1/2/4/8-GPU scaling.
 
 Workload (config.workload = "C3"): the dragon-scale stand-in — 819 200-triangle
 torus knot (data/dragon.obj is absent from the reference), 1920x1080, Phong +
-hard shadows + reflections depth 4, default camera — synthetic, generated in
-process. One "step" = one full frame with the scene, BVH and framebuffer resident in
-HBM. Throughput setting (defaults): a launch renders 8 successive frames
-(rt_render_device_frames), two launches are in flight on alternating HIP streams,
-8x8-pixel primary tiles; every frame is rendered in full, K steps = K frames.
-`--frames-per-launch 1 --frames-in-flight 1` is the strictly serial loop.
+hard shadows + reflections depth 4 — synthetic, generated in process. One "step" =
+one full frame with the scene, BVH and framebuffer resident in HBM. EVERY FRAME HAS
+ITS OWN CAMERA POSE: the default trackball orbits the scene once over the timed
+steps (the reference renders one camera per renderRayTracing call, or one camera
+per thread in CLI mode, src/main.cpp:512-531); rays are counted per pose in an
+untimed pass. Throughput setting (defaults): a launch renders 8 successive frames
+(rt_render_device_frames), three launches are in flight on HIP streams of their own,
+8x8-pixel primary tiles; every frame is rendered in full, K steps = K frames; when 8
+does not divide K the frames go out as equal launches (20 steps = 3 launches of 7, 7
+and 6 — never single frames). Before anything is timed every buffer is allocated and
+every launch shape has run on every launch stream (StripRenderer.prepare), whatever
+--warmup says. `frame_ms_serial` is the other extreme: one frame per launch, one
+launch at a time, host-synchronised, the library's default 4x4-pixel tiles.
 
 N GPUs: one process per GPU; the frame's 8-row strips are dealt round-robin to
-the ranks, each renders its strips into a packed buffer, an RCCL all-gather
-over xGMI assembles them and a de-interleave kernel writes the reference's
-row-flipped frame (strong scaling: the frame is fixed).
+the ranks, each renders its strips into a packed buffer, the strips are gathered on
+rank 0 over RCCL / xGMI (one grouped send / receive per peer) and a de-interleave
+kernel writes the reference's row-flipped frame there (strong scaling: the frame
+is fixed).
 
 JSON line (rank 0): the contract's keys plus
   roofline      dominant kernel k_trace_level: ALGORITHMIC bytes per launch
-                 / average launch duration measured with HIP
-                events on the launch stream during the timed steps; peak 8 TB/s.
+                (mean over the timed poses) / average duration of
+                the launches of the main shape, measured with HIP events on the
+                launch streams during the timed steps; peak 8 TB/s. `traffic`,
+                `valu` (instruction count against the VALU issue peak) and
+                `salu_insts` come from the PMC passes of the same launch shape
+                (profiles/pmc_<workload>.json, tools/r2_profile.sh).
   cpu_baseline  the CPU oracle (kind "port": the repo's restatement of the
-                reference path, OpenMP rows) timed on this host on the same frame.
+                reference path, OpenMP guided rows like src/render.cpp:277-281) on
+                this host: whole frames on all cores, a sample on one core.
 """
 import argparse
 import importlib
@@ -67,7 +80,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="successive frames on alternating HIP streams, so that the tail of frame k (a few long "
-                         "path trees) overlaps the start of the next launch (default 2); "
+                         "path trees) overlaps the start of the next launches (default 3); "
                          "1 = strictly one frame at a time")
     ap.add_argument("--tile-log", type=int, nargs=2, default=None, metavar=("W", "H"),
                     help="primary tile = 2^W x 2^H pixels per wave (default: 3 3 with several frames per launch and "
@@ -92,7 +105,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.frames_in_flight is None:
-        args.frames_in_flight = 2
+        args.frames_in_flight = 3
     if args.frames_per_launch is None:
         args.frames_per_launch = 8
     if args.exchange_batch is None:
@@ -301,19 +314,24 @@ def main():
                                 "VALU-issue bound — see valu"}
             pj = ROOT / "profiles" / f"pmc_{args.workload}.json"
             if pj.exists() and world == 1:
+                # PMC passes of the bench's launch shape (tools/r2_profile.sh: same tile shape, frames per launch as
+                # recorded there, ONE launch in flight so that a launch's counters are its own); launches of another
+                # frame count are priced per frame
                 pm = json.load(open(pj))
-                if pm.get("frames_per_launch") == main_size and pm.get("tile_log") == [
-                        int(args.tile_log[0]) if args.tile_log else (3 if fpl > 1 else 2),
-                        int(args.tile_log[1]) if args.tile_log else (3 if fpl > 1 or renderer.flight > 1 else 2)]:
-                    roofline["traffic"] = pm.get("hbm_bytes_per_launch")
+                tiles = [int(args.tile_log[0]), int(args.tile_log[1])] if args.tile_log else ([3, 3] if fpl > 1 else [2, 2])
+                if pm.get("tile_log") == tiles and pm.get("frames_per_launch"):
+                    k = main_size / pm["frames_per_launch"]
+                    if pm.get("hbm_bytes_per_launch"):
+                        roofline["traffic"] = int(pm["hbm_bytes_per_launch"] * k)
                     v = pm.get("valu_insts_per_launch")
                     if v:
                         peak_issue = 256 * 4 * 2.4e9 / 2   # CUs x SIMDs x clock / 2 cycles per wave64 VALU instruction
-                        roofline["valu"] = {"insts": int(v), "peak_issue_per_s": peak_issue,
-                                            "frac": round(v / avg_launch_s / peak_issue, 4),
+                        roofline["valu"] = {"insts": int(v * k), "peak_issue_per_s": peak_issue,
+                                            "frac": round(v * k / avg_launch_s / peak_issue, 4),
                                             "active_lane_frac": pm.get("valu_active_lane_frac"),
-                                            "source": f"profiles/{pj.name} (rocprofv3 --pmc, {pm.get('command', '')})"}
-                        roofline["salu_insts"] = pm.get("salu_insts_per_launch")
+                                            "source": f"profiles/{pj.name}: rocprofv3 --pmc of {pm.get('command', '')}; "
+                                                      f"{pm['frames_per_launch']}-frame launches, priced per frame"}
+                        roofline["salu_insts"] = int((pm.get("salu_insts_per_launch") or 0) * k)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(cfg, data, scenes)
