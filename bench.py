@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--exchange", default="gather", choices=["gather", "allgather"],
                     help="several GPUs: gather the strips on rank 0 (grouped send / receive, one peer per xGMI link of "
                          "the root; default) or all-gather them to every rank")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="rt_set_option(NAME, VALUE) before the run (tuning experiments; results do not depend on them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not bracket trace kernels with HIP events during the timed steps")
@@ -171,6 +173,9 @@ def main():
     if args.tile_log:
         rt.set_option("tile_wlog", args.tile_log[0])
         rt.set_option("tile_hlog", args.tile_log[1])
+    for kv in args.set:
+        k_, v_ = kv.split("=")
+        rt.set_option(k_, int(v_))
     renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, rank, world, strip_rows=STRIP_ROWS,
                                       frames_in_flight=args.frames_in_flight, exchange_always=args.exchange_always,
                                       exchange_batch=args.exchange_batch, exchange=args.exchange)

@@ -23,7 +23,7 @@ LIB_PATH = CSRC / "librt_whitted.so"
 EXPORTS = [
     "rt_last_error", "rt_device_info", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
-    "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_camera_from_trackball", "rt_render",
+    "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_bvh_wide_check", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_device_frames", "rt_render_frames", "rt_render_sharded", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
     "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_profile_read_launches", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
     "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp", "rt_bloom_device",
@@ -92,6 +92,13 @@ class Bvh:
         self.lib._check(self.lib.c.rt_bvh_export(self.handle, aabb.ctypes.data, meta.ctypes.data, order.ctypes.data))
         return aabb, meta, order
 
+    def wide_check(self) -> dict:
+        """structural self-check of the wide traversal tree (host only); raises RtError when inconsistent"""
+        st = (C.c_uint64 * 8)()
+        self.lib._check(self.lib.c.rt_bvh_wide_check(self.handle, st))
+        return dict(nodes=st[0], groups=st[1], depth=st[2], triangles=st[3], empty_slots=st[4], internal=st[5],
+                    has_wide_tree=bool(st[6]))
+
     def close(self):
         if self.handle:
             self.lib.c.rt_bvh_destroy(self.handle)
@@ -123,6 +130,7 @@ class Library:
         for n in ("rt_bvh_num_levels", "rt_bvh_num_leaves", "rt_bvh_num_nodes", "rt_bvh_num_prims"):
             getattr(c, n).argtypes = [C.c_void_p]
         c.rt_bvh_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        c.rt_bvh_wide_check.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         c.rt_bloom_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(abi.RenderParams), C.c_void_p]
         c.rt_camera_from_trackball.argtypes = [C.c_float, C.c_float, C.c_float * 3, C.c_float, C.c_float * 3,
                                                C.POINTER(abi.Camera)]

@@ -66,6 +66,7 @@ struct HostBvh {
     bool wide_ok = false;
     uint32_t wide_depth = 0;
     void build_wide(); // host_wide.cpp; needs records
+    std::string check_wide(uint64_t stats[8]) const; // structural self-check ("" = consistent)
     uint32_t root_ref = 0, root_cnt = 0; // root_cnt: count word (rt_layout.h)
     int num_levels = 0, num_leaves = 0;
     uint32_t max_leaf = 0;

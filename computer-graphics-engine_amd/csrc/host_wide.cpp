@@ -236,4 +236,90 @@ void HostBvh::build_wide()
     wide_ok = true;
 }
 
+// Structural self-check of the wide tree (host only; rt_bvh_wide_check): every triangle of `records` sits in exactly
+// one slot, every child box encloses the bounds of every triangle below it, child words are well-formed.
+// stats: [0] nodes, [1] leaf groups, [2] depth, [3] triangles found, [4] empty child slots, [5] internal children
+std::string HostBvh::check_wide(uint64_t stats[8]) const
+{
+    for (int i = 0; i < 8; i++)
+        stats[i] = 0;
+    if (!wide_ok)
+        return "";
+    const size_t n = records.size();
+    if (wide_index.size() != wide_slot_src.size() || wide_slot_src.size() % 4 != 0 || ref_leaf_of.size() != n)
+        return "array sizes";
+    std::vector<uint8_t> seen(n, 0);
+    struct Item {
+        uint32_t node, depth;
+    };
+    std::vector<Item> todo { { 0u, 1u } };
+    std::vector<uint8_t> visited(wide_nodes.size(), 0);
+    // bounds of the triangles below a node, bottom-up: second pass over a post-order list
+    std::vector<uint32_t> order;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.node >= wide_nodes.size() || visited[it.node])
+            return "node index out of range or reached twice";
+        visited[it.node] = 1;
+        order.push_back(it.node);
+        stats[2] = std::max<uint64_t>(stats[2], it.depth);
+        for (int k = 0; k < 4; k++) {
+            const uint32_t r = wide_nodes[it.node].ref[k];
+            if (r == kWideEmpty)
+                stats[4]++;
+            else if (!wide_is_leaf(r))
+                stats[5]++, todo.push_back({ r, it.depth + 1 });
+        }
+    }
+    stats[0] = order.size();
+    if (order.size() != wide_nodes.size())
+        return "unreachable nodes";
+    std::vector<WBox> below(wide_nodes.size());
+    for (size_t oi = order.size(); oi-- > 0;) { // children come after their parent in `order`
+        const uint32_t ni = order[oi];
+        const WideNode& wn = wide_nodes[ni];
+        WBox all;
+        all.reset();
+        for (int k = 0; k < 4; k++) {
+            const uint32_t r = wn.ref[k];
+            if (r == kWideEmpty)
+                continue;
+            WBox cb;
+            cb.reset();
+            if (wide_is_leaf(r)) {
+                const uint32_t g = wide_leaf_group(r), cnt = wide_leaf_count(r);
+                if ((size_t)g * 4 + 4 > wide_slot_src.size())
+                    return "group out of range";
+                stats[1]++;
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t src = wide_slot_src[(size_t)g * 4 + j];
+                    if (j >= cnt) {
+                        if (src != 0xffffffffu)
+                            return "padding slot holds a triangle";
+                        continue;
+                    }
+                    if (src >= n || seen[src] || wide_index[(size_t)g * 4 + j] != src)
+                        return "triangle missing, repeated or mis-indexed";
+                    seen[src] = 1;
+                    stats[3]++;
+                    const PrimRecord& pr = records[src];
+                    cb.add_point(pr.v0), cb.add_point(pr.v1), cb.add_point(pr.v2);
+                }
+            } else {
+                cb = below[r];
+            }
+            const float lo[3] = { wn.lox[k], wn.loy[k], wn.loz[k] }, hi[3] = { wn.hix[k], wn.hiy[k], wn.hiz[k] };
+            for (int a = 0; a < 3; a++)
+                if (!(lo[a] <= cb.lo[a]) || !(hi[a] >= cb.hi[a]))
+                    return "a child box does not enclose the triangles below it";
+            all.add(cb.lo, cb.hi);
+        }
+        below[ni] = all;
+    }
+    if (stats[3] != n)
+        return "not every triangle is in the tree";
+    return "";
+}
+
 } // namespace rt

@@ -33,7 +33,7 @@ std::atomic<int> g_leaf_flush { 16 };
 std::atomic<int> g_wide { 1 };
 // rt_set_option("xcd_order", 1): the tile dispatch order deals screen blocks to the XCDs (rt_kernels.h CameraArgs)
 // rt_set_option("prefetch", 1): the wide engine touches the next node's line at the end of a step
-std::atomic<int> g_xcd_order { 1 }, g_prefetch { 0 }, g_xcd_block { 4 };
+std::atomic<int> g_xcd_order { 1 }, g_prefetch { 0 }, g_xcd_block { 4 }, g_frame_major { 1 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
 std::atomic<int> g_tile_wlog { 2 }, g_tile_hlog { 2 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
@@ -402,20 +402,23 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
     // screen blocks of 2^xcd_block pixels a side, in tiles
     const uint32_t bpl = (uint32_t)g_xcd_block.load();
     const uint32_t bxlog = bpl > cam.tile_wlog ? bpl - cam.tile_wlog : 0u, bylog = bpl > cam.tile_hlog ? bpl - cam.tile_hlog : 0u;
-    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period, xcd, (int64_t)cam.tile_x0, (int64_t)cam.tile_y0, (int64_t)bxlog, (int64_t)bylog };
+    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period, xcd, (int64_t)cam.tile_x0, (int64_t)cam.tile_y0, (int64_t)bxlog, (int64_t)bylog, (int64_t)g_frame_major.load() };
     if (key != sc.order_key || !sc.order.p) {
         // built on the device (k_tile_ring_*): the launched grid follows the camera, and a host-built order
         // would put an upload + synchronisation into every launch of a moving camera
         const size_t n = (size_t)(gw * gh);
         const int64_t rmax = std::max(std::max(std::llabs(cx), std::llabs(gw - 1 - cx)) * tw,
             std::max(std::llabs(cy), std::llabs(std::min(gh, period) - 1 - cy)) * th);
-        const int64_t step = std::min(tw, th);
+        // rings four tiles wide: the order inside a ring is arbitrary anyway, and the 64 consecutive tiles of a
+        // sorting wave then fall into a handful of rings (one atomic each) instead of one ring per tile
+        const int64_t step = 4 * std::min(tw, th);
         rt::TileOrderArgs o;
         o.gw = (uint32_t)gw, o.n_tiles = (uint32_t)n;
         o.xcd_order = (uint32_t)xcd, o.xcd_bxlog = bxlog, o.xcd_bylog = bylog, o.tile_x0 = cam.tile_x0, o.tile_y0 = cam.tile_y0;
         o.tw = tw, o.th = th, o.cx = cx, o.cy = cy, o.period = period, o.step = step;
         o.n_rings = (uint32_t)(rmax / step + 2);
         o.n_frames = (uint32_t)std::max<int64_t>(1, (gh + period - 1) / period);
+        o.frame_major = g_frame_major.load() ? 1u : 0u;
         // sized for the whole tile grid once: a reallocation frees memory, which waits for the device
         HIP_TRY(sc.order.reserve((size_t)(((cam.vwidth + tw - 1) / tw) * ((cam.n_rows + th - 1) / th))));
         HIP_TRY(sc.order_rings.reserve(8u * (size_t)rt::kMaxFramesPerLaunch * ((size_t)cam.vwidth + (size_t)cam.n_rows + 4u)));
@@ -735,6 +738,10 @@ int rt_set_option(const char* name, int value)
         g_xcd_block.store(value);
         return RT_OK;
     }
+    if (name && strcmp(name, "frame_major") == 0) { // several frames per launch: an XCD's tile list frame after frame (1) or centre first over all frames (0)
+        g_frame_major.store(value != 0);
+        return RT_OK;
+    }
     if (name && strcmp(name, "prefetch") == 0) {
         g_prefetch.store(value != 0);
         return RT_OK;
@@ -861,6 +868,17 @@ int rt_bvh_num_levels(const rt_bvh* bvh) { return bvh ? bvh->host.num_levels : 0
 int rt_bvh_num_leaves(const rt_bvh* bvh) { return bvh ? bvh->host.num_leaves : 0; }
 int rt_bvh_num_nodes(const rt_bvh* bvh) { return bvh ? (int)bvh->host.nodes.size() : 0; }
 int rt_bvh_num_prims(const rt_bvh* bvh) { return bvh ? (int)bvh->host.prim_order.size() : 0; }
+
+int rt_bvh_wide_check(const rt_bvh* bvh, uint64_t stats[8])
+{
+    if (!bvh || !stats)
+        return fail(RT_ERR_INVALID, "rt_bvh_wide_check: null argument");
+    const std::string err = bvh->host.check_wide(stats);
+    stats[6] = bvh->host.wide_ok ? 1u : 0u;
+    if (!err.empty())
+        return fail(RT_ERR_INVALID, "rt_bvh_wide_check: " + err);
+    return RT_OK;
+}
 
 int rt_bvh_export(const rt_bvh* bvh, float* node_aabb, int32_t* node_meta, int32_t* prim_order)
 {

@@ -151,6 +151,7 @@ struct TileOrderArgs {
     uint32_t gw, n_tiles; // launched grid width in tiles, tiles in it
     uint32_t xcd_order, xcd_bxlog, xcd_bylog, tile_x0, tile_y0; // xcd_order: sort key = (XCD of the tile, frame, ring)
     uint32_t n_frames;                                         // frames in the launch (tile rows / period)
+    uint32_t frame_major; // 1: an XCD's list goes frame after frame (each centre first); 0: centre first over all frames
     int64_t tw, th, cx, cy, period, step;
     uint32_t n_rings;
     uint32_t* rings; // n_rings counters (scratch)

@@ -1281,7 +1281,7 @@ RT_DEV uint32_t tile_ring(const TileOrderArgs& a, uint32_t tile)
     if (a.xcd_order) // eight lists, one per XCD; in a list frame after frame (a frame's share of the scene fits the
                      // XCD's L2, eight frames' shares do not), each frame centre first
         q += ((int64_t)tile_xcd((uint32_t)tx + a.tile_x0, (uint32_t)(ty % a.period) + a.tile_y0, a.xcd_bxlog, a.xcd_bylog)
-                     * a.n_frames + ty / a.period) * a.n_rings;
+                     * a.n_frames + (a.frame_major ? ty / a.period : 0)) * a.n_rings;
     return (uint32_t)q;
 }
 // One atomic per (wave, ring) instead of one per tile: the 64 consecutive tiles of a wave lie in a handful of

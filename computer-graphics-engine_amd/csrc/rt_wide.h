@@ -117,16 +117,6 @@ struct WideWalk {
         lq_n += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) + 4u * (uint32_t)__builtin_popcountll(b2);
     }
 
-    RT_DEV void queue_leaf(bool want, uint32_t r, uint32_t ref)
-    {
-        const uint64_t m = ballot(want);
-        if (m) {
-            if (want) // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
-                L.wlq[lq_n + prefix_count(m)] = (ref & 0xffffffu) | (((ref >> 29) & 3u) << 24) | (r << 26);
-            lq_n += (uint32_t)__builtin_popcountll(m);
-        }
-    }
-
     // ---- node phase: private deques + work stealing, as in the exact engine -------------------------------
     // Lanes with `seed` start at the root with their own ray. Returns the mask of ray slots for the exact engine.
     RT_DEV uint64_t run(bool seed)

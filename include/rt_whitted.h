@@ -234,6 +234,12 @@ int rt_bvh_num_levels(const rt_bvh* bvh);
 int rt_bvh_num_leaves(const rt_bvh* bvh);
 int rt_bvh_num_nodes(const rt_bvh* bvh);
 int rt_bvh_num_prims(const rt_bvh* bvh);
+/* Host-only structural check of the traversal tree the kernels walk (csrc/rt_wide.h: our own 4-wide SAH tree over
+ * the triangles; the reference's tree above is what decides results): every triangle in exactly one leaf slot, every
+ * child box enclosing the triangles below it. stats: [0] nodes [1] leaf groups [2] depth [3] triangles [4] empty
+ * child slots [5] internal children [6] 1 if the scene has a wide tree (0: spheres, tiny scene: exact engine only). */
+int rt_bvh_wide_check(const rt_bvh* bvh, uint64_t stats[8]);
+
 /* Debug/parity export of the reference-shaped tree: post-order nodes
  * (root = last). node_aabb: n*6 floats (lower,upper); node_meta: n*6 int32
  * {leaf, depth, beg, end, left, right} (left/right = -1 for leaves);
