@@ -357,6 +357,7 @@ def main():
                        "rays_bvh_traversed": per_frame(rays_bvh),
                        "rays_culled_before_traversal": per_frame(total.get("rays_culled", 0)),
                        "rays_exact_engine": round(total.get("rays_exact", 0) / args.steps, 2),
+                       "rays_shadow_skipped": per_frame(total.get("rays_shadow_skipped", 0)),
                        "rays_reference_equivalent": per_frame(total["rays_ref_equiv"]),
                        "rays_primary": per_frame(total["rays_primary"]), "rays_shadow": per_frame(total["rays_shadow"]),
                        "rays_reflect": per_frame(total["rays_reflect"]), "box_tests": per_frame(total["box_tests"]),

@@ -33,7 +33,7 @@ std::atomic<int> g_leaf_flush { 16 };
 std::atomic<int> g_wide { 1 };
 // rt_set_option("xcd_order", 1): the tile dispatch order deals screen blocks to the XCDs (rt_kernels.h CameraArgs)
 // rt_set_option("prefetch", 1): the wide engine touches the next node's line at the end of a step
-std::atomic<int> g_xcd_order { 1 }, g_prefetch { 0 }, g_xcd_block { 4 }, g_frame_major { 1 };
+std::atomic<int> g_xcd_order { 1 }, g_prefetch { 0 }, g_xcd_block { 4 }, g_frame_major { 1 }, g_skip_unlit { 1 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
 std::atomic<int> g_tile_wlog { 2 }, g_tile_hlog { 2 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
@@ -499,6 +499,7 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.lean = !area_lights && !f.enableNormalInterp && !f.enableTextureMapping && bvh->scene->host.spheres.empty() ? 1u : 0u;
     a.tile_cull = g_tile_cull.load() && !counters_dev ? 1u : 0u; // the counting pass traces every primary ray
     a.tile_cull_count = g_tile_cull.load() && counters_dev ? 1u : 0u;
+    a.skip_unlit = g_skip_unlit.load() ? 1u : 0u;
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
     bool rect = false;
@@ -740,6 +741,10 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "frame_major") == 0) { // several frames per launch: an XCD's tile list frame after frame (1) or centre first over all frames (0)
         g_frame_major.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "skip_unlit") == 0) { // 0: trace the shadow rays of unlit hits too (what the reference does; same bits)
+        g_skip_unlit.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "prefetch") == 0) {

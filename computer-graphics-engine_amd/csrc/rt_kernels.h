@@ -69,6 +69,7 @@ struct LevelArgs {
     size_t level_stride;      // floats between the `direct` planes of consecutive levels
     uint32_t merge_next;      // 1: trace a level's first shadow rays together with the next level's reflection rays
     uint32_t tile_cull;       // 1: primary tiles that cannot reach the scene bounds skip the traversal
+    uint32_t skip_unlit;      // 1: no shadow ray where the light's colour at the hit is exactly zero (shade_hit)
     uint32_t tile_cull_count; // counting pass: 1 = count (and still trace) the primary rays tile_cull would skip
     uint32_t lean;            // 1: point lights only (or soft shadows off), triangles only, no normal interpolation /
                               //    textures: the lean kernel variant renders it

@@ -213,7 +213,7 @@ RT_DEV uint32_t wave_sum(uint32_t v)
 }
 
 struct RayCounts {
-    uint32_t closest = 0, shadow = 0, hits = 0, queued = 0, culled = 0;
+    uint32_t closest = 0, shadow = 0, hits = 0, queued = 0, culled = 0, skipped = 0;
 };
 
 RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCounts& rc, int32_t level, uint32_t lane)
@@ -222,7 +222,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
     const uint32_t closest = wave_sum(rc.closest), shadow = wave_sum(rc.shadow);
     const uint32_t hits = wave_sum(rc.hits), queued = wave_sum(rc.queued);
     const uint32_t node_fetch = wave_sum(lc.node_fetch), tri_fetch = wave_sum(lc.tri_fetch), grp = wave_sum(lc.grp);
-    const uint32_t culled = wave_sum(rc.culled), exact = wave_sum(lc.exact_rays);
+    const uint32_t culled = wave_sum(rc.culled), exact = wave_sum(lc.exact_rays), skipped = wave_sum(rc.skipped);
     if (lane == 0) {
         auto add = [](uint64_t* p, uint64_t v) {
             if (v)
@@ -231,7 +231,8 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
         add(&out->rays, (uint64_t)closest + shadow);
         add(level == 0 ? &out->rays_primary : &out->rays_reflect, closest);
         add(&out->rays_shadow, shadow);
-        add(&out->rays_ref_equiv, ((uint64_t)closest + shadow) << (level > 0 ? level : 0));
+        add(&out->rays_ref_equiv, ((uint64_t)closest + shadow + skipped) << (level > 0 ? level : 0));
+        add(&out->rays_shadow_skipped, skipped);
         add(&out->box_tests, box);
         add(&out->tri_tests, tri);
         add(&out->sphere_tests, sph);
@@ -283,6 +284,15 @@ RT_DEV void light_sample(const LightRec RT_CONST_AS* L, int32_t kind, const Leve
         const V3 topColor = horWeight * c3 + (1 - horWeight) * c2;
         lcol = verWeight * topColor + (1 - verWeight) * bottomColor;
     }
+}
+
+// computeLightContribution multiplies a light sample's colour by its visibility (light.cpp:121,135,153). Where
+// every component of the colour is +-0 or NaN — a surface facing away from the light: diffuse = kd * Lc * 0, no
+// specular term — the product has the same bits for visibility 0 and 1, so the sample's shadow ray is not traced
+// (it is reported as rays_shadow_skipped, not as a traversed ray). Exact; rt_set_option("skip_unlit", 0) traces them.
+RT_DEV bool visibility_is_moot(V3 c)
+{
+    return (c.x == 0.0f || c.x != c.x) && (c.y == 0.0f || c.y != c.y) && (c.z == 0.0f || c.z != c.z);
 }
 
 // The next level's closest-hit query, traced TOGETHER with this level's first shadow query
@@ -350,6 +360,11 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                 const uint32_t pix_s = (uint32_t)__shfl((int)pixel, src, 64);
                 const bool try_known = use_bvh && prune && sv.wide_ok != 0u;
                 int32_t known = -1; // what blocked this lane's previous sample is tried first (wide_known_blocker)
+                HitL hs; // the hit this lane's samples belong to (for visibility_is_moot)
+                hs.normal = mk(__shfl(h.normal.x, src, 64), __shfl(h.normal.y, src, 64), __shfl(h.normal.z, src, 64));
+                hs.kd = mk(__shfl(h.kd.x, src, 64), __shfl(h.kd.y, src, 64), __shfl(h.kd.z, src, 64));
+                hs.ks = mk(__shfl(h.ks.x, src, 64), __shfl(h.ks.y, src, 64), __shfl(h.ks.z, src, 64));
+                hs.shininess = __shfl(h.shininess, src, 64), hs.transparency = 1.0f, hs.texture = -1;
                 for (int32_t s0 = 0; s0 < nsamp; s0 += (int32_t)batch) {
                     const int32_t s_mine = s0 + (int32_t)kk;
                     const bool mine = kk < batch && s_mine < nsamp;
@@ -358,9 +373,16 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                     const RayL sray = shadow_ray(rs, ts, lp);
                     float st = 1.0f;
                     int32_t spos;
-                    bool need = mine, by_known = false;
-                    if (try_known && ballot(mine && known >= 0)) {
-                        if (mine && known >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)known, lc))
+                    const bool moot = a.skip_unlit != 0u && visibility_is_moot(compute_shading(lp, lcq, rs, ts, hs));
+                    bool need = mine && !moot, by_known = false;
+                    if (COUNT && mine) { // counted where the ray is traced (the lane that carries the sample)
+                        if (moot)
+                            rc.skipped++;
+                        else
+                            rc.shadow++;
+                    }
+                    if (try_known && ballot(need && known >= 0)) {
+                        if (need && known >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)known, lc))
                             need = false, by_known = true;
                     }
                     traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
@@ -375,8 +397,6 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                         if (hit)
                             color = compute_shading(lpos, lcol, ray, t, h);
                         acc = acc + color * visibility;
-                        if (COUNT && hit)
-                            rc.shadow++;
                     }
                 }
                 s_begin = nsamp;
@@ -388,15 +408,24 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                 V3 lpos, lcol;
                 light_sample(L, kind, a, pixel, level, li, s, lpos, lcol);
                 float visibility = 1.0f;
+                V3 color = mk(0.0f, 0.0f, 0.0f);
+                if (hit)
+                    color = compute_shading(lpos, lcol, ray, t, h);
                 if (trace_shadow) { // testVisibilityLightSample, light.cpp:49-73
                     const RayL sray = shadow_ray(ray, t, lpos);
                     float st = 1.0f;
                     int32_t spos;
-                    if (COUNT && hit)
-                        rc.shadow++;
-                    bool need = hit;
-                    if (try_blocker && ballot(hit && last_blocker >= 0)) {
-                        if (hit && last_blocker >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)last_blocker, lc)) {
+                    // with enableTransparency the visibility is a material's transparency, not 0 / 1: every ray is traced
+                    const bool moot = a.skip_unlit != 0u && !(GENERAL && (flags & F_TRANSPARENCY)) && visibility_is_moot(color);
+                    bool need = hit && !moot;
+                    if (COUNT && hit) {
+                        if (moot)
+                            rc.skipped++;
+                        else
+                            rc.shadow++;
+                    }
+                    if (try_blocker && ballot(need && last_blocker >= 0)) {
+                        if (need && last_blocker >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)last_blocker, lc)) {
                             visibility = 0.0f;
                             need = false;
                         }
@@ -409,7 +438,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                         RayL q;
                         q.o = mk(__shfl(sray.o.x, src, 64), __shfl(sray.o.y, src, 64), __shfl(sray.o.z, src, 64));
                         q.d = mk(__shfl(sray.d.x, src, 64), __shfl(sray.d.y, src, 64), __shfl(sray.d.z, src, 64));
-                        const bool hit_lo = __shfl((int)hit, src, 64) != 0;
+                        const bool hit_lo = __shfl((int)need, src, 64) != 0;
                         bool act = hit_lo;
                         float tq = 1.0f;
                         if (!upper) {
@@ -435,9 +464,6 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                             visibility = hit_transparency(sv, flags, spos);
                     }
                 }
-                V3 color = mk(0.0f, 0.0f, 0.0f);
-                if (hit)
-                    color = compute_shading(lpos, lcol, ray, t, h);
                 if (is_point)
                     result = result + color * visibility;
                 else

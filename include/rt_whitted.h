@@ -188,6 +188,9 @@ typedef struct rt_counters {
     uint64_t group_tests;    /* conservative ray / triangle-group box tests of the leaf phase (pruned policy only) */
     uint64_t rays_culled;    /* primary rays (counted in `rays`) of tiles the timed launch ends in its prologue or never
                               * launches: their ray pyramid misses the scene bounds, so they never touch the BVH */
+    uint64_t rays_shadow_skipped; /* shadow-ray call equivalents NOT traced (and not counted in `rays` / `rays_shadow`):
+                              * the light's colour at the hit is exactly zero (surface facing away: every component
+                              * +-0 or NaN), so colour x visibility has the same bits whatever the visibility */
     uint64_t rays_exact;     /* rays traced by the exact-topology engine: all of them where the wide tree does not
                               * apply (spheres, unpruned policy, brute force, tiny scenes), else the rays that are not
                               * all_ok or that the wide engine handed back (csrc/rt_wide.h) */
