@@ -315,8 +315,8 @@ def main():
                         "other_launches": [[x[0], round(x[1] * 1e3, 2)] for x in launch_ms if x[0] != main_size],
                         "launches_in_flight": renderer.flight,
                         "note": "HBM is the roofline SURVEY.md 8(d) prescribes, but not the ceiling that binds: the "
-                                "kernel's bytes come from L1/L2/Infinity Cache (traffic << algorithmic) and it is "
-                                "VALU-issue bound — see valu"}
+                                "kernel's bytes come from L1/L2/Infinity Cache (traffic << algorithmic); what binds is "
+                                "instruction issue per wave and the latency of dependent fetches (DESIGN.md 3) — see valu"}
             pj = ROOT / "profiles" / f"pmc_{args.workload}.json"
             if pj.exists() and world == 1:
                 # PMC passes of the bench's launch shape (tools/r2_profile.sh: same tile shape, frames per launch as
