@@ -295,12 +295,13 @@ RT_DEV bool visibility_is_moot(V3 c)
     return (c.x == 0.0f || c.x != c.x) && (c.y == 0.0f || c.y != c.y) && (c.z == 0.0f || c.z != c.z);
 }
 
-// The next level's closest-hit query, traced TOGETHER with this level's first shadow query
-// (traverse<Q_MIXED>): pixel lanes (all < 32) carry their reflection ray in their own ray slot,
-// lane p + 32 carries pixel p's shadow ray. One traversal with twice the rays instead of two:
-// better lane use in the node phase and half as many serial traversals per path tree.
+// The next level's closest-hit query, traced TOGETHER with this level's first shadow query (traverse_pair): the
+// reflection rays take ray slots 0..31 and the shadow rays slots 32..63 by their rank among the wave's rays of
+// that kind, whatever lanes hold them — taken level by level whenever each kind fits its 32 slots (sparse deeper
+// levels of 64-pixel tiles, every level of tiles of up to 32 pixels). One traversal with twice the rays instead of
+// two: better lane use in the node phase and half as many serial traversals per path tree.
 struct MergeNext {
-    bool enabled = false; // pixel lanes are all < 32 and the launch runs fused
+    bool enabled = false; // the launch runs fused (and merge_next is on)
     bool done = false;    // the merged traversal ran: pos / t hold the next level's closest hit
     bool spawn = false;   // this lane has a reflection ray
     RayL refl;
@@ -430,28 +431,21 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                             need = false;
                         }
                     }
-                    if (!GENERAL && mg && mg->enabled && !mg->done) {
-                        const uint32_t lane = lane_id();
-                        const bool upper = lane >= 32u;
-                        const int src = (int)(lane & 31u);
-                        // lane p + 32 takes pixel p's shadow ray
-                        RayL q;
-                        q.o = mk(__shfl(sray.o.x, src, 64), __shfl(sray.o.y, src, 64), __shfl(sray.o.z, src, 64));
-                        q.d = mk(__shfl(sray.d.x, src, 64), __shfl(sray.d.y, src, 64), __shfl(sray.d.z, src, 64));
-                        const bool hit_lo = __shfl((int)need, src, 64) != 0;
-                        bool act = hit_lo;
-                        float tq = 1.0f;
-                        if (!upper) {
-                            q = mg->refl;
-                            act = mg->spawn;
-                            tq = kFltMax;
-                        }
-                        int32_t pq;
-                        traverse<Q_MIXED, COUNT, LEAN>(sv, use_bvh, prune, act, q, tq, pq, lc, wl);
+                    // this level's first shadow rays + the next level's reflection rays in ONE traversal when each kind
+                    // fits its 32 ray slots (traverse_pair): rays go to slots by their rank, whatever lanes hold them
+                    const uint64_t m_c = (!GENERAL && mg && mg->enabled && !mg->done) ? ballot(mg->spawn) : 0ull;
+                    const uint64_t m_a = ballot(need);
+                    if (!GENERAL && mg && mg->enabled && !mg->done && use_bvh && sv.root_cnt == 0u
+                        && __builtin_popcountll(m_c) <= 32 && __builtin_popcountll(m_a) <= 32) {
+                        float tq = kFltMax;
+                        int32_t pq, pa;
+                        traverse_pair<COUNT, LEAN>(sv, prune, mg->spawn, mg->refl, prefix_count(m_c), tq, pq, need, sray,
+                            32u + prefix_count(m_a), 1.0f, pa, lc, wl);
                         mg->pos = pq, mg->t = tq, mg->done = true;
-                        spos = __shfl(pq, (int)(lane | 32u), 64);
-                        if (spos >= 0)
+                        if (pa >= 0) {
                             visibility = 0.0f;
+                            last_blocker = pa;
+                        }
                     } else if (!GENERAL || !(flags & F_TRANSPARENCY)) {
                         traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
                         if (spos >= 0) {
@@ -937,8 +931,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     int32_t level = first_level;
     MergeNext mg;
     mg.refl.o = mk(0, 0, 0), mg.refl.d = mk(0, 0, 0);
-    // merged traversals need every pixel lane below 32 (tiles of up to 32 pixels) and a fused launch
-    mg.enabled = a.fused != 0u && a.merge_next != 0u && (ballot(active) >> 32) == 0ull;
+    // merged traversals (traverse_pair) need a fused launch; they are taken level by level where the rays fit
+    mg.enabled = a.fused != 0u && a.merge_next != 0u;
     for (;; level++) {
     // ---- closest hit (bvh.intersect, render.cpp:31) — unless the previous level's merged
     //      traversal (MergeNext) already found it

@@ -527,4 +527,103 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
 #endif
 }
 
+// Two queries in one traversal, packed by ray SLOT: up to 32 closest-hit rays in slots 0..31 and up to 32 any-hit
+// (shadow) rays in slots 32..63, whatever lanes they come from — a lane may bring one of each (its next-level
+// reflection ray and its shadow ray). k_trace_level uses it for a level's first shadow rays + the next level's
+// reflection rays whenever both kinds fit: half as many dependent traversals per path tree, and sparse levels fill
+// the wave twice as well. Requires use_bvh and an internal root (the caller checks); slots must be distinct.
+// Engines as in traverse(): the wide engine for all_ok rays, the exact-topology engine for the others and for the
+// slots the wide engine hands back; the winner checks run in the lanes that own the rays.
+template <bool COUNT, bool NO_SPHERES>
+RT_DEV void traverse_pair(const SceneView& sv, bool prune, bool want_c, const RayL& ray_c, uint32_t slot_c, float& t_c,
+    int32_t& pos_c, bool want_a, const RayL& ray_a, uint32_t slot_a, float t_a, int32_t& pos_a, LaneCounters& lc, WaveLds& L)
+{
+    pos_c = pos_a = -1;
+    if (ballot(want_c || want_a) == 0)
+        return;
+#ifdef RT_TIMELINE
+    lc.tl_traversals++;
+#endif
+    const uint32_t lane = lane_id();
+    prune = prune && sv.prune_ok != 0u;
+    const bool wide = prune && sv.wide_ok != 0u;
+    const RayInv inv_c = make_ray_inv(ray_c, sv.extent), inv_a = make_ray_inv(ray_a, sv.extent);
+    const bool fast_c = want_c && wide && inv_c.all_ok(), fast_a = want_a && wide && inv_a.all_ok();
+    // slot table in L.xfer (free between the engines' runs): 0 empty, 1 wide engine, 2 exact-topology engine
+    L.xfer[lane] = 0u;
+    wave_lds_fence();
+    if (want_c) {
+        L.rayA[slot_c] = make_float4(ray_c.o.x, ray_c.o.y, ray_c.o.z, ray_c.d.x);
+        L.rayB[slot_c] = make_float4(ray_c.d.y, ray_c.d.z, t_c, __uint_as_float(inv_c.guard));
+        L.rayC[slot_c] = make_float4(inv_c.y[0], inv_c.y[1], inv_c.y[2], inv_c.slack);
+        L.best[slot_c] = kNoHit;
+        L.xfer[slot_c] = fast_c ? 1u : 2u;
+    }
+    if (want_a) {
+        L.rayA[slot_a] = make_float4(ray_a.o.x, ray_a.o.y, ray_a.o.z, ray_a.d.x);
+        L.rayB[slot_a] = make_float4(ray_a.d.y, ray_a.d.z, t_a, __uint_as_float(inv_a.guard));
+        L.rayC[slot_a] = make_float4(inv_a.y[0], inv_a.y[1], inv_a.y[2], inv_a.slack);
+        L.best[slot_a] = kNoHit;
+        L.xfer[slot_a] = fast_a ? 1u : 2u;
+    }
+    wave_lds_fence();
+    const uint32_t mine = L.xfer[lane]; // the state of the slot this lane seeds
+    wave_lds_fence();
+    bool redo_c = want_c && !fast_c, redo_a = want_a && !fast_a;
+    if (wide) {
+        uint32_t flush_at = sv.leaf_flush < kWideFlushMax ? sv.leaf_flush : kWideFlushMax;
+        WideWalk<Q_MIXED, COUNT> ww { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 128u),
+            make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u), 0u,
+            flush_at < 1u ? 1u : flush_at };
+        const uint64_t back = ww.run(mine == 1u);
+        if (fast_c) {
+            const unsigned long long key = L.best[slot_c];
+            redo_c = ((back >> slot_c) & 1ull) != 0ull || (key != kNoHit && !wide_winner_stands<COUNT>(sv, ray_c, inv_c, key, lc));
+        }
+        if (fast_a) {
+            const unsigned long long key = L.best[slot_a];
+            redo_a = ((back >> slot_a) & 1ull) != 0ull || (key != kNoHit && !wide_winner_stands<COUNT>(sv, ray_a, inv_a, key, lc));
+        }
+        wave_lds_fence();
+        L.xfer[lane] = 0u;
+        wave_lds_fence();
+    }
+    if (redo_c)
+        L.best[slot_c] = kNoHit, L.xfer[slot_c] = 2u;
+    if (redo_a)
+        L.best[slot_a] = kNoHit, L.xfer[slot_a] = 2u;
+    if (COUNT)
+        lc.exact_rays += (redo_c ? 1u : 0u) + (redo_a ? 1u : 0u);
+    wave_lds_fence();
+    const bool slow = L.xfer[lane] == 2u;
+    wave_lds_fence();
+    if (ballot(slow)) {
+        Walk<Q_MIXED, COUNT> w { sv, L, make_rsrc(sv.leaf, sv.n_prims * 48u), make_rsrc(sv.nodes, sv.n_pairs * 64u),
+            make_rsrc(sv.leaf_grouped, sv.n_groups * 4u * 48u), make_rsrc(sv.groups, sv.n_groups * 32u),
+            !NO_SPHERES && sv.prune_ok == 0u, lc, lane, prune, 0u, ray_c, inv_c };
+        w.lane_engine(0u, slow, sv.root_ref, 0.0f);
+        w.flush_leaves(1u);
+        wave_lds_fence();
+    }
+    if (want_c) {
+        const unsigned long long key = L.best[slot_c];
+        if (key != kNoHit) { // the reported primitive's own t, with its exact bits (-0.0f included)
+            pos_c = (int32_t)key_index(key);
+            const PrimRecord rec = sv.prims[pos_c];
+            float tt;
+            if (!NO_SPHERES && (rec.kind_mat & 0x80000000u))
+                sphere_candidate(rec, ray_c, t_c, tt);
+            else
+                tt = tri_plane_t(rec, ray_c);
+            t_c = tt;
+        }
+    }
+    if (want_a) {
+        const unsigned long long key = L.best[slot_a];
+        if (key != kNoHit)
+            pos_a = (int32_t)key_index(key);
+    }
+    wave_lds_fence(); // the caller may reuse L for the next query
+}
+
 } // namespace rt
