@@ -25,7 +25,7 @@ EXPORTS = [
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_bvh_wide_check", "rt_camera_from_trackball", "rt_render",
     "rt_render_device", "rt_render_device_frames", "rt_render_frames", "rt_render_sharded", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
-    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_profile_read_launches", "rt_debug_div_check", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
+    "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_profile_read_launches", "rt_debug_div_check", "rt_debug_tile_order", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
     "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp", "rt_bloom_device",
 ]
 
@@ -170,6 +170,8 @@ class Library:
         c.rt_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         c.rt_debug_div_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]
+        c.rt_debug_tile_order.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_int32), C.c_void_p, C.c_uint64,
+                                                            C.POINTER(C.c_uint32)]
         c.rt_rand31.restype = C.c_uint32
         c.rt_rand31.argtypes = [C.c_uint32] * 6
 
@@ -377,6 +379,18 @@ class Library:
         bad, fast = C.c_uint64(), C.c_uint64()
         self._check(self.c.rt_debug_div_check(seed, mode, n_samples, C.byref(bad), C.byref(fast)))
         return int(bad.value), int(fast.value), (self.c.rt_last_error() or b"").decode()
+
+    def debug_tile_order(self, width: int, n_rows: int, n_frames: int, tile_wlog: int, tile_hlog: int, rect=None):
+        """(order, info) of the tile dispatch order the render calls would build (rt_debug_tile_order)."""
+        tw, th = 1 << tile_wlog, 1 << tile_hlog
+        cap = ((width + tw - 1) // tw) * ((n_rows + th - 1) // th)
+        out = np.zeros(cap, dtype=np.uint32)
+        info = (C.c_uint32 * 20)()
+        r = (C.c_int32 * 4)(*rect) if rect is not None else None
+        self._check(self.c.rt_debug_tile_order(width, n_rows, n_frames, tile_wlog, tile_hlog, r,
+                                               out.ctypes.data_as(C.c_void_p), cap, info))
+        info = [int(v) for v in info]
+        return out[:info[0] * info[1]], info
 
     def rand31(self, seed, pixel, level, light, sample, dim) -> int:
         return int(self.c.rt_rand31(seed, pixel, level, light, sample, dim))

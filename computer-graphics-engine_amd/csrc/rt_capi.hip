@@ -33,7 +33,7 @@ std::atomic<int> g_leaf_flush { 16 };
 std::atomic<int> g_wide { 1 };
 // rt_set_option("xcd_order", 1): the tile dispatch order deals screen blocks to the XCDs (rt_kernels.h CameraArgs)
 // rt_set_option("prefetch", 1): the wide engine touches the next node's line at the end of a step
-std::atomic<int> g_xcd_order { 1 }, g_prefetch { 0 }, g_xcd_block { 4 }, g_frame_major { 1 }, g_skip_unlit { 1 };
+std::atomic<int> g_xcd_order { 1 }, g_prefetch { 0 }, g_xcd_block { 4 }, g_frame_major { 1 }, g_skip_unlit { 1 }, g_order_one_launch { 1 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
 std::atomic<int> g_tile_wlog { 2 }, g_tile_hlog { 2 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
@@ -384,8 +384,11 @@ bool host_launch_rect(const rt_bvh* bvh, rt::CameraArgs& cam)
 // tiles that see geometry (around the centre of the scene's screen rectangle) must start early
 // or their chains form a tail with most of the chip idle (tools/timeline.py). Purely a
 // scheduling choice — results do not depend on it.
-int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
+// zero / n_zero: words the caller wants cleared on `stream` before its trace launch; *zeroed tells whether the
+// order launch did that on its way.
+int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_t* zero, uint32_t n_zero, bool* zeroed)
 {
+    *zeroed = false;
     if (!g_tile_order.load() || cam.super_log != 0)
         return RT_OK;
     const int64_t tw = 1 << cam.tile_wlog, th = 1 << cam.tile_hlog;
@@ -402,7 +405,7 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
     // screen blocks of 2^xcd_block pixels a side, in tiles
     const uint32_t bpl = (uint32_t)g_xcd_block.load();
     const uint32_t bxlog = bpl > cam.tile_wlog ? bpl - cam.tile_wlog : 0u, bylog = bpl > cam.tile_hlog ? bpl - cam.tile_hlog : 0u;
-    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period, xcd, (int64_t)cam.tile_x0, (int64_t)cam.tile_y0, (int64_t)bxlog, (int64_t)bylog, (int64_t)g_frame_major.load() };
+    const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period, xcd, (int64_t)cam.tile_x0, (int64_t)cam.tile_y0, (int64_t)bxlog, (int64_t)bylog, (int64_t)g_frame_major.load(), (int64_t)g_order_one_launch.load() };
     if (key != sc.order_key || !sc.order.p) {
         // built on the device (k_tile_ring_*): the launched grid follows the camera, and a host-built order
         // would put an upload + synchronisation into every launch of a moving camera
@@ -425,23 +428,39 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream)
         if (n > sc.order.n || 8u * (size_t)o.n_frames * (size_t)o.n_rings > sc.order_rings.n)
             return fail(RT_ERR_INVALID, "internal error: tile order scratch too small");
         o.rings = sc.order_rings.p, o.order = sc.order.p;
-        rt::launch_tile_order(o, stream);
-        HIP_TRY(hipGetLastError());
-        // XCD-aware order: the lengths of the eight lists (tile_xcd over the launched grid, row by row in runs of
-        // one screen block)
+        // XCD-aware order: the lengths of the eight lists (tile_xcd over the launched grid). A block column's XCD is
+        // (bx + 3 by) % 8: count the tiles of a row per residue of bx once, then rotate that by 3 by per tile row.
         memset(sc.xcd_count, 0, sizeof(sc.xcd_count));
         if (xcd) {
             const int64_t B = (int64_t)1 << bxlog;
+            uint32_t per_res[8] = {};
+            for (int64_t tx = 0; tx < gw;) {
+                const int64_t atx = tx + (int64_t)cam.tile_x0;
+                const int64_t run = std::min<int64_t>(B - (atx & (B - 1)), gw - tx);
+                per_res[(atx >> bxlog) & 7] += (uint32_t)run;
+                tx += run;
+            }
             for (int64_t ty = 0; ty < gh; ty++) {
-                const uint32_t aty = (uint32_t)(ty % period) + cam.tile_y0;
-                for (int64_t tx = 0; tx < gw;) {
-                    const int64_t atx = tx + (int64_t)cam.tile_x0;
-                    const int64_t run = std::min<int64_t>(B - (atx & (B - 1)), gw - tx);
-                    sc.xcd_count[rt::tile_xcd((uint32_t)atx, aty, bxlog, bylog)] += (uint32_t)run;
-                    tx += run;
-                }
+                const uint32_t by = ((uint32_t)(ty % period) + cam.tile_y0) >> bylog;
+                for (uint32_t c = 0; c < 8; c++)
+                    sc.xcd_count[rt::tile_xcd(c << bxlog, by << bylog, bxlog, bylog)] += per_res[c];
             }
         }
+        const uint64_t keys_per_list = (uint64_t)o.n_rings * (xcd ? o.n_frames : 1u);
+        // one launch for a lone frame (it waits for its tile order: count / scan / scatter + a memset cost it ~30 us
+        // more); launches of several frames run beside other launches, and there the three kernels — which queue up
+        // behind the running trace kernel and so stagger the launches — measured 1 % better (profiles/r02_notes.md)
+        const int one = g_order_one_launch.load();
+        o.one_launch = (one == 2 || (one == 1 && o.n_frames == 1)) && keys_per_list <= rt::kTileOrderLdsKeys ? 1u : 0u;
+        o.zero = nullptr, o.n_zero = 0;
+        for (uint32_t k = 0, base = 0; k < 8; k++) {
+            o.list_base[k] = xcd ? base : 0u;
+            base += sc.xcd_count[k];
+        }
+        if (o.one_launch && zero)
+            o.zero = zero, o.n_zero = n_zero, *zeroed = true;
+        rt::launch_tile_order(o, stream);
+        HIP_TRY(hipGetLastError());
         sc.order_key = key;
     }
     cam.xcd_order = (uint32_t)xcd;
@@ -475,7 +494,6 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
             HIP_TRY(sc.qitem[b].reserve(n_items));
             HIP_TRY(sc.qpixel[b].reserve(n_items));
         }
-    HIP_TRY(hipMemsetAsync(sc.counts.p, 0, ((size_t)n_levels + 1) * sizeof(uint32_t), stream));
     if (counters_dev)
         HIP_TRY(hipMemsetAsync(counters_dev, 0, sizeof(rt_counters), stream));
 
@@ -502,7 +520,7 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.skip_unlit = g_skip_unlit.load() ? 1u : 0u;
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
-    bool rect = false;
+    bool rect = false, counts_zeroed = false;
     if (source == rt::SRC_CAMERA && !counters_dev && (flags & rt::F_ACCEL) && !(flags & rt::F_NO_PRUNE)) {
         rect = host_launch_rect(bvh, a.cam);
         if (cam.n_frames > 1) { // the union of the frames' rectangles (their row ranges are all kept: a row list)
@@ -540,10 +558,12 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
         } else {
             a.cam.tile_x0 = a.cam.tile_y0 = a.cam.tiles_w = a.cam.tiles_h = 0;
         }
-        const int rc = tile_order_for(sc, a.cam, stream);
+        const int rc = tile_order_for(sc, a.cam, stream, sc.counts.p, (uint32_t)n_levels + 1u, &counts_zeroed);
         if (rc != RT_OK)
             return rc;
     }
+    if (!counts_zeroed)
+        HIP_TRY(hipMemsetAsync(sc.counts.p, 0, ((size_t)n_levels + 1) * sizeof(uint32_t), stream));
     a.state = sc.state.p;
     a.n_items = n_items;
     a.counters = counters_dev;
@@ -741,6 +761,12 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "frame_major") == 0) { // several frames per launch: an XCD's tile list frame after frame (1) or centre first over all frames (0)
         g_frame_major.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "order_one_launch") == 0) { // the tile order in one launch (counters in LDS): 1 for lone frames, 2 for every launch; 0: count / scan / scatter kernels
+        if (value < 0 || value > 2)
+            return fail(RT_ERR_INVALID, "rt_set_option: order_one_launch must be 0, 1 (lone frames) or 2 (every launch)");
+        g_order_one_launch.store(value);
         return RT_OK;
     }
     if (name && strcmp(name, "skip_unlit") == 0) { // 0: trace the shadow rays of unlit hits too (what the reference does; same bits)
@@ -1398,6 +1424,40 @@ int rt_intersect_batch(const rt_bvh* cbvh, rt_ray* rays, uint32_t n_rays, const 
         HIP_TRY(hipMemcpy(hits, sc.hits.p, (size_t)n_rays * sizeof(rt_hit), hipMemcpyDeviceToHost));
     if (counters)
         HIP_TRY(hipMemcpy(counters, sc.counters.p, sizeof(rt_counters), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_debug_tile_order(int32_t width, int32_t n_rows, int32_t n_frames, int32_t tile_wlog, int32_t tile_hlog,
+    const int32_t rect[4], uint32_t* order_out, uint64_t cap, uint32_t info[20])
+{
+    if (!order_out || !info || width <= 0 || n_rows <= 0 || n_frames < 1 || n_frames > rt::kMaxFramesPerLaunch || tile_wlog < 0
+        || tile_wlog > 3 || tile_hlog < 0 || tile_hlog > 3 || n_rows % (n_frames << tile_hlog) != 0)
+        return fail(RT_ERR_INVALID, "rt_debug_tile_order: bad argument");
+    Scratch sc;
+    rt::CameraArgs cam;
+    memset(&cam, 0, sizeof(cam));
+    cam.width = width, cam.vwidth = width, cam.spp = 1, cam.height = n_rows / n_frames, cam.n_rows = n_rows;
+    cam.tile_wlog = (uint32_t)tile_wlog, cam.tile_hlog = (uint32_t)tile_hlog;
+    cam.n_frames = n_frames, cam.frame_rows = n_rows / n_frames;
+    std::vector<int32_t> rows_stub(1, 0);
+    if (n_frames > 1)
+        cam.rows = rows_stub.data(); // only tested for being a row list
+    if (rect)
+        cam.tile_x0 = (uint32_t)rect[0], cam.tile_y0 = (uint32_t)rect[1], cam.tiles_w = (uint32_t)rect[2], cam.tiles_h = (uint32_t)rect[3];
+    bool zeroed = false;
+    const int rc = tile_order_for(sc, cam, nullptr, nullptr, 0, &zeroed);
+    if (rc != RT_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    const uint32_t tw = 1u << tile_wlog, th = 1u << tile_hlog;
+    const uint64_t gw = cam.tiles_w ? cam.tiles_w : ((uint64_t)width + tw - 1) / tw;
+    const uint64_t gh = cam.tiles_w ? cam.tiles_h : ((uint64_t)n_rows + th - 1) / th;
+    if (!cam.order || gw * gh > cap)
+        return fail(RT_ERR_INVALID, "rt_debug_tile_order: no order built, or the output is too small");
+    HIP_TRY(hipMemcpy(order_out, cam.order, gw * gh * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    info[0] = (uint32_t)gw, info[1] = (uint32_t)gh, info[2] = cam.xcd_order, info[3] = cam.launch_waves;
+    for (int k = 0; k < 8; k++)
+        info[4 + k] = cam.xcd_base[k], info[12 + k] = cam.xcd_count[k];
     return RT_OK;
 }
 

@@ -157,7 +157,13 @@ struct TileOrderArgs {
     uint32_t n_rings;
     uint32_t* rings; // n_rings counters (scratch)
     uint32_t* order; // out: launch position -> tile index
+    // one-launch form (k_tile_order_lists: one workgroup per list, counters in LDS)
+    uint32_t one_launch;   // keys per list fit the LDS
+    uint32_t list_base[8]; // first place of list x in `order`
+    uint32_t* zero;        // NULL, or n_zero words the launch clears on its way (the level counters of the trace launch)
+    uint32_t n_zero;
 };
+constexpr uint32_t kTileOrderLdsKeys = 12288; // one-launch form: sort keys per list that fit the LDS (48 KB)
 
 extern uint32_t g_lds_pad;
 #if defined(RT_DIAG) && RT_DIAG == 2

@@ -1363,6 +1363,82 @@ __global__ __launch_bounds__(256) void k_tile_ring_scatter(const TileOrderArgs a
         a.order[place] = tile;
 }
 
+// The same order in ONE launch: workgroup x builds list x (the tiles of XCD x's screen blocks; without the XCD
+// order there is one list of all tiles) with its counters in LDS — count, scan, scatter with two barriers instead
+// of two kernel boundaries and a memset (a lone frame spends ~60 us in those, tools/timeline of the serial frame).
+// The places inside a ring are whatever the LDS atomics give.
+__global__ __launch_bounds__(1024) void k_tile_order_lists(const TileOrderArgs a)
+{
+    extern __shared__ uint32_t lds_keys[];
+    const uint32_t list = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+    const uint32_t kpl = a.n_rings * (a.xcd_order ? a.n_frames : 1u); // keys per list
+    uint32_t* hist = lds_keys;
+    uint32_t* part = lds_keys + kpl;
+    if (list == 0 && a.zero)
+        for (uint32_t i = tid; i < a.n_zero; i += nt)
+            a.zero[i] = 0u;
+    for (uint32_t i = tid; i < kpl; i += nt)
+        hist[i] = 0u;
+    __syncthreads();
+    // the list's tiles: in tile row ty the blocks whose column bx has (bx + 3 by) % 8 == list, i.e. every eighth
+    const uint32_t gh = a.n_tiles / a.gw;
+    const uint32_t B = 1u << a.xcd_bxlog, bx_lo = a.tile_x0 >> a.xcd_bxlog;
+    const uint32_t nb = ((a.tile_x0 + a.gw - 1u) >> a.xcd_bxlog) - bx_lo + 1u;
+    const uint32_t per_row = a.xcd_order ? ((nb + 7u) / 8u) << a.xcd_bxlog : a.gw;
+    const uint32_t items = gh * per_row;
+    auto tile_of = [&](uint32_t it, uint32_t& tile) {
+        const uint32_t ty = it / per_row, r = it - ty * per_row;
+        if (!a.xcd_order) {
+            tile = it;
+            return true;
+        }
+        const uint32_t by = ((uint32_t)(ty % (uint32_t)a.period) + a.tile_y0) >> a.xcd_bylog;
+        const uint32_t bx = bx_lo + ((list - 3u * by - bx_lo) & 7u) + 8u * (r >> a.xcd_bxlog);
+        const uint32_t atx = (bx << a.xcd_bxlog) + (r & (B - 1u));
+        tile = ty * a.gw + (atx - a.tile_x0);
+        return atx >= a.tile_x0 && atx < a.tile_x0 + a.gw;
+    };
+    const uint32_t key0 = a.xcd_order ? list * kpl : 0u;
+    for (uint32_t it = tid; it < items; it += nt) {
+        uint32_t tile;
+        if (tile_of(it, tile)) {
+            const uint32_t k = tile_ring(a, tile) - key0;
+            if (k < kpl)
+                atomicAdd(&hist[k], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the kpl counters
+    const uint32_t per = (kpl + nt - 1u) / nt, b = tid * per;
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < b + per && i < kpl; i++)
+        sum += hist[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < nt; o <<= 1) {
+        const uint32_t v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum + a.list_base[list];
+    for (uint32_t i = b; i < b + per && i < kpl; i++) {
+        const uint32_t c = hist[i];
+        hist[i] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (uint32_t it = tid; it < items; it += nt) {
+        uint32_t tile;
+        if (tile_of(it, tile)) {
+            const uint32_t k = tile_ring(a, tile) - key0;
+            const uint32_t place = k < kpl ? atomicAdd(&hist[k], 1u) : a.n_tiles;
+            if (place < a.n_tiles) // holds by construction (the host's list lengths are the lists'); never write outside
+                a.order[place] = tile;
+        }
+    }
+}
+
 uint32_t grid_for_waves(uint64_t waves) { return (uint32_t)((waves + (kBlock / 64) - 1) / (kBlock / 64)); }
 
 uint64_t camera_waves(const CameraArgs& c)
@@ -1443,6 +1519,14 @@ void launch_tile_order(const TileOrderArgs& a, hipStream_t s)
 {
     if (a.n_tiles == 0)
         return;
+    if (a.one_launch) {
+        // a lone frame gets a whole CU's worth of threads; several frames per launch run beside other launches' trace
+        // kernels, where a workgroup of 16 waves would wait for a CU to drain
+        const uint32_t nt = a.n_frames > 1 ? 256u : 1024u;
+        const uint32_t kpl = a.n_rings * (a.xcd_order ? a.n_frames : 1u);
+        hipLaunchKernelGGL(k_tile_order_lists, dim3(a.xcd_order ? 8u : 1u), dim3(nt), (kpl + nt) * sizeof(uint32_t), s, a);
+        return;
+    }
     (void)hipMemsetAsync(a.rings, 0, (size_t)a.n_rings * (a.xcd_order ? 8u * a.n_frames : 1u) * sizeof(uint32_t), s);
     const uint32_t grid = (a.n_tiles + 255u) / 256u;
     hipLaunchKernelGGL(k_tile_ring_count, dim3(grid), dim3(256), 0, s, a);

@@ -214,7 +214,10 @@ int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len);
  * Scheduling / tuning options, none of which changes any result: "fused" (1: all
  * recursion levels in one launch), "fused_from", "tile_wlog" / "tile_hlog" (primary
  * tile = 2^w x 2^h pixels per wave), "tile_order" (1: centre-first dispatch),
- * "leaf_flush", "min_waves", "super_log". Unknown names return RT_ERR_INVALID. */
+ * "leaf_flush", "min_waves", "super_log", "tile_cull", "launch_rect", "merge_next", "wide" (0: the
+ * exact-topology engine alone), "xcd_order" / "xcd_block" (screen blocks of 2^v pixels a side per XCD),
+ * "frame_major", "order_one_launch" (the tile order built in one launch: 1 for lone frames, 2 always, 0 never), "skip_unlit"
+ * (0: trace the shadow rays of unlit hits too), "prefetch". Unknown names return RT_ERR_INVALID. */
 int rt_set_option(const char* name, int value);
 
 /* Select the HIP device used by subsequent creates on this thread. */
@@ -373,6 +376,15 @@ int rt_profile_read_launches(rt_bvh* bvh, void* hip_stream, double* launch_ms, u
  *    took the fast path. ------------------------------------------------------- */
 int rt_debug_div_check(uint32_t seed, uint32_t mode, uint64_t n_samples, uint64_t* mismatches,
                        uint64_t* fast_path_samples);
+
+/* -- Device self-check of the tile dispatch order (a scheduling choice, but one that must start every tile of
+ *    the launched grid exactly once): builds the order of a launch of n_frames frames of n_rows / n_frames rows
+ *    and `width` columns, tiles of 2^tile_wlog x 2^tile_hlog pixels, launched sub-grid rect = {tile_x0, tile_y0,
+ *    tiles_w, tiles_h} (NULL: the whole grid), exactly as the render calls do under the current options, and
+ *    copies it to order_out (host, `cap` entries). info: [0] grid width, [1] grid height in tiles, [2] XCD order
+ *    in use, [3] launch positions, [4..11] first place of XCD list x, [12..19] its length. ------------------- */
+int rt_debug_tile_order(int32_t width, int32_t n_rows, int32_t n_frames, int32_t tile_wlog, int32_t tile_hlog,
+                        const int32_t rect[4], uint32_t* order_out, uint64_t cap, uint32_t info[20]);
 
 /* -- Multi-GPU strip de-interleave: gathered packed strips
  *    of all ranks → the reference's row-flipped frame. gathered_dev holds

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where a bench frame's time goes, by switching path features on one at a time (throughput setting, moving camera):
+"""Where a bench frame's time goes, by switching path features on one at a time (throughput setting, or with
+PHASE_LONE=1 the serial frame; moving camera):
 primary rays only -> + shading -> + hard shadows -> + reflections depth 1..4. ms per frame and rays per frame."""
 import importlib, math, os, sys, time
 from pathlib import Path
@@ -19,7 +20,9 @@ POSES = 32
 fovy, aspect, look_at, dist_, rot0 = scenes.default_camera_args(W, H)
 cams = [rt.camera(fovy, aspect, look_at, dist_, (rot0[0], rot0[1] + 2 * math.pi * k / POSES, rot0[2])) for k in range(POSES)]
 stream = torch.cuda.current_stream().cuda_stream
-rt.set_option("tile_wlog", 3); rt.set_option("tile_hlog", 3); rt.set_option("leaf_flush", 32)
+LONE = os.environ.get("PHASE_LONE", "0") == "1"  # one frame per launch, host-synchronised, 4x4 tiles (the serial frame)
+if not LONE:
+    rt.set_option("tile_wlog", 3); rt.set_option("tile_hlog", 3); rt.set_option("leaf_flush", 32)
 variants = [
     ("primary rays only", dict(enableAccelStructure=1), 0),
     ("+ shading", dict(enableAccelStructure=1, enableShading=1), 0),
@@ -32,11 +35,20 @@ bvh = rt.bvh(rt.scene(data), abi.Features.make(enableAccelStructure=1))
 for name, flags, depth in variants:
     f = abi.Features.make(**flags)
     p = abi.RenderParams.make(depth=depth)
-    R = sharding.StripRenderer(rt, bvh, cams[0], f, p, W, H, frames_in_flight=2)
+    R = sharding.StripRenderer(rt, bvh, cams[0], f, p, W, H, frames_in_flight=1 if LONE else 2)
     c = R.count_rays(stream, cam=cams[0])
-    R.prepare(stream, (8,))
+    R.prepare(stream, (1,) if LONE else (8,))
     best = 1e9
-    for rep in range(3):
+    for rep in range(3 if LONE else 0):
+        ts = []
+        for k in range(0, POSES, 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            R.step(stream, cams=[cams[k]])
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        best = min(best, float(np.mean(ts)) * 1e3)
+    for rep in range(0 if LONE else 3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 0

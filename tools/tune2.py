@@ -49,7 +49,7 @@ def apply(s, tiles):
         for kv in s.split(","):
             k, x = kv.split("=")
             if k not in ("tile_wlog", "tile_hlog", "leaf_flush"):  # those are set per mode above
-                defaults.setdefault(k, {"xcd_order": 1, "xcd_block": 4, "wide": 1}.get(k, int(os.environ.get("TUNE_DEFAULT_" + k.upper(), "0"))))
+                defaults.setdefault(k, {"xcd_order": 1, "xcd_block": 4, "wide": 1, "fused": 1, "merge_next": 1, "skip_unlit": 1, "frame_major": 1, "tile_cull": 1, "launch_rect": 1, "tile_order": 1, "order_one_launch": 1}.get(k, int(os.environ.get("TUNE_DEFAULT_" + k.upper(), "0"))))
             rt.set_option(k, int(x))
 
 
