@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--exchange", default="gather", choices=["gather", "allgather"],
                     help="several GPUs: gather the strips on rank 0 (grouped send / receive, one peer per xGMI link of "
                          "the root; default) or all-gather them to every rank")
+    ap.add_argument("--no-window", action="store_true",
+                    help="several ranks, gather form: send whole strips instead of the part inside rt_frame_rect")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="rt_set_option(NAME, VALUE) before the run (tuning experiments; results do not depend on them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,7 +180,7 @@ def main():
         rt.set_option(k_, int(v_))
     renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, rank, world, strip_rows=STRIP_ROWS,
                                       frames_in_flight=args.frames_in_flight, exchange_always=args.exchange_always,
-                                      exchange_batch=args.exchange_batch, exchange=args.exchange)
+                                      exchange_batch=args.exchange_batch, exchange=args.exchange, window=not args.no_window)
 
     # ---- camera poses: every frame its own (the reference renders one camera per renderRayTracing call, or one
     #      camera per thread in CLI mode, src/main.cpp:512-531): the default trackball orbits the scene once over
@@ -248,12 +250,14 @@ def main():
         for s_ in launch_streams:
             rt.profile_read(bvh, s_, reset=True)
     renderer.start_log()
+    exch0 = renderer.exchanges["bytes"] if hasattr(renderer, "exchanges") else 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     run_frames(0, args.steps)
     renderer.finish()
+    exch_bytes = (renderer.exchanges["bytes"] - exch0) if hasattr(renderer, "exchanges") else 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -317,6 +321,13 @@ def main():
                         "note": "HBM is the roofline SURVEY.md 8(d) prescribes, but not the ceiling that binds: the "
                                 "kernel's bytes come from L1/L2/Infinity Cache (traffic << algorithmic); what binds is "
                                 "instruction issue per wave and the latency of dependent fetches (DESIGN.md 3) — see valu"}
+            # the launches in flight share the chip: a launch's own duration understates what the chip does by the
+            # overlap factor (summed launch durations over the wall time of the timed region)
+            overlap = sum(x[1] for x in launch_ms) / 1e3 / elapsed
+            chip = ab_rank / elapsed / 1e9
+            roofline["chip_wide"] = {"launch_overlap": round(overlap, 3), "achieved": round(chip, 2),
+                                     "frac": round(chip / HBM_PEAK_GBS, 4),
+                                     "note": "all timed launches' algorithmic bytes over the wall time of the timed region"}
             pj = ROOT / "profiles" / f"pmc_{args.workload}.json"
             if pj.exists() and world == 1:
                 # PMC passes of the bench's launch shape (tools/r2_profile.sh: same tile shape, frames per launch as
@@ -337,6 +348,7 @@ def main():
                                             "source": f"profiles/{pj.name}: rocprofv3 --pmc of {pm.get('command', '')}; "
                                                       f"{pm['frames_per_launch']}-frame launches, priced per frame"}
                         roofline["salu_insts"] = int((pm.get("salu_insts_per_launch") or 0) * k)
+                        roofline["chip_wide"]["valu_frac"] = round(v / pm["frames_per_launch"] * args.steps / elapsed / peak_issue, 4)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(cfg, data, scenes)
@@ -369,6 +381,10 @@ def main():
                        + (f"+{renderer.flight}-launches-in-flight" if renderer.flight > 1 else "")
                        + (f"+{fpl}-frames-per-launch" if fpl > 1 else "")
                        + ("+REHEARSAL-gloo-one-device" if rehearsal else ""),
+                       "exchange": ({"form": args.exchange, "window": bool(getattr(renderer, "window", False)),
+                                     "root_receives_bytes_per_frame": int(exch_bytes / max(args.steps, 1)),
+                                     "whole_strips_would_be": int(W * H * 12 * (world - 1) / world)}
+                                    if renderer.sharded and hasattr(renderer, "exchanges") else None),
                        "launch_frames": sizes if len(sizes) <= 8 else {str(z): sizes.count(z) for z in sorted(set(sizes))},
                        "device": devname, "bvh_build_s": round(build_s, 3)},
             "roofline": roofline, "cpu_baseline": cpu,

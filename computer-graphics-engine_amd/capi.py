@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_last_error", "rt_device_info", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_update_lights", "rt_bvh_build", "rt_bvh_destroy", "rt_bvh_num_levels", "rt_bvh_num_leaves",
     "rt_bvh_num_nodes", "rt_bvh_num_prims", "rt_bvh_export", "rt_bvh_wide_check", "rt_camera_from_trackball", "rt_render",
-    "rt_render_device", "rt_render_device_frames", "rt_render_frames", "rt_render_sharded", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
+    "rt_render_device", "rt_render_device_frames", "rt_frame_rect", "rt_render_frames", "rt_render_sharded", "rt_render_hits", "rt_trace_batch", "rt_intersect_batch", "rt_deinterleave_strips", "rt_deinterleave_frames",
     "rt_rand31", "rt_profile_enable", "rt_profile_read", "rt_profile_read_launches", "rt_debug_div_check", "rt_debug_tile_order", "rt_set_option", "rt_load_obj", "rt_load_preset", "rt_loaded_scene_desc",
     "rt_loaded_scene_destroy", "rt_io_last_error", "rt_write_bmp", "rt_bloom_device",
 ]
@@ -140,6 +140,8 @@ class Library:
         c.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Features),
                                        C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        c.rt_frame_rect.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.c_int32, C.POINTER(abi.Features),
+                                    C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         c.rt_render_device_frames.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.c_int32, C.POINTER(abi.Features),
                                               C.POINTER(abi.RenderParams), C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                               C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p]
@@ -379,6 +381,15 @@ class Library:
         bad, fast = C.c_uint64(), C.c_uint64()
         self._check(self.c.rt_debug_div_check(seed, mode, n_samples, C.byref(bad), C.byref(fast)))
         return int(bad.value), int(fast.value), (self.c.rt_last_error() or b"").decode()
+
+    def frame_rect(self, bvh: Bvh, cams, features, params, width: int, height: int):
+        """(x0, y0, x1, y1): columns [x0, x1) x image rows [y0, y1) outside of which the frames rendered for the
+        cameras `cams` (one, or a sequence: the union) are vec3(0)."""
+        cams = list(cams) if isinstance(cams, (list, tuple)) else [cams]
+        arr = (abi.Camera * len(cams))(*cams)
+        r = (C.c_int32 * 4)()
+        self._check(self.c.rt_frame_rect(bvh.handle, arr, len(cams), C.byref(features), C.byref(params), width, height, r))
+        return tuple(int(v) for v in r)
 
     def debug_tile_order(self, width: int, n_rows: int, n_frames: int, tile_wlog: int, tile_hlog: int, rect=None):
         """(order, info) of the tile dispatch order the render calls would build (rt_debug_tile_order)."""

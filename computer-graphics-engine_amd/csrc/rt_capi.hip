@@ -1097,6 +1097,42 @@ int rt_render_device(const rt_bvh* cbvh, const rt_camera* camera, const rt_featu
     return enqueue_frame(bvh, sc, *features, *params, cam, fold, rows == nullptr && !packed, counters_dev, stream);
 }
 
+int rt_frame_rect(const rt_bvh* cbvh, const rt_camera* cameras, int32_t n_cameras, const rt_features* features,
+    const rt_render_params* params, int32_t width, int32_t height, int32_t rect[4])
+{
+    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
+    if (!bvh || !cameras || !rect || n_cameras < 1)
+        return fail(RT_ERR_INVALID, "rt_frame_rect: null argument");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30)
+        return fail(RT_ERR_INVALID, "rt_frame_rect: bad resolution");
+    int rc = check_features(features, bvh);
+    if (rc == RT_OK)
+        rc = check_params(params);
+    if (rc != RT_OK)
+        return rc;
+    rect[0] = 0, rect[1] = 0, rect[2] = width, rect[3] = height;
+    // exactly the condition under which the render calls leave tiles unlaunched (enqueue_trace) — the pixels of
+    // those tiles are the ones k_fold fills with vec3(0) without looking at anything
+    const uint32_t flags = feature_flags(*features);
+    if (!(flags & rt::F_ACCEL) || (flags & rt::F_NO_PRUNE))
+        return RT_OK;
+    int64_t x0 = width, y0 = height, x1 = 0, y1 = 0;
+    for (int32_t k = 0; k < n_cameras; k++) {
+        rt::CameraArgs cam = camera_args(cameras[k], width, height);
+        camera_samples(cam, *features, *params);
+        cam.tile_wlog = cam.tile_hlog = 3; // the coarsest tile the library launches: the rectangle is aligned outward to it
+        if (!host_launch_rect(bvh, cam))
+            return RT_OK; // the whole frame
+        const int64_t spp = cam.spp;
+        x0 = std::min<int64_t>(x0, ((int64_t)cam.tile_x0 * 8) / spp);
+        x1 = std::max<int64_t>(x1, std::min<int64_t>(width, (((int64_t)cam.tile_x0 + cam.tiles_w) * 8 + spp - 1) / spp));
+        y0 = std::min<int64_t>(y0, (int64_t)cam.tile_y0 * 8);
+        y1 = std::max<int64_t>(y1, std::min<int64_t>(height, ((int64_t)cam.tile_y0 + cam.tiles_h) * 8));
+    }
+    rect[0] = (int32_t)x0, rect[1] = (int32_t)y0, rect[2] = (int32_t)x1, rect[3] = (int32_t)y1;
+    return RT_OK;
+}
+
 int rt_render_device_frames(const rt_bvh* cbvh, const rt_camera* cameras, int32_t n_frames,
     const rt_features* features, const rt_render_params* params, int32_t width, int32_t height, const int32_t* rows,
     int32_t n_rows, int32_t packed, float* rgb_dev, uint64_t frame_stride_floats, void* hip_stream)

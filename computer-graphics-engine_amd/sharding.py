@@ -93,6 +93,71 @@ def gather_strips(gathered, local, root=None):
         w.wait()  # orders the current stream after the transfer; the host does not wait
 
 
+def rows_in_window(rows, y0: int, y1: int):
+    """[l0, l1): positions in a rank's (ascending) image-row list `rows` of the rows that lie in [y0, y1)."""
+    return int(np.searchsorted(rows, y0)), int(np.searchsorted(rows, y1))
+
+
+def stale_region(dirty, new):
+    """Bookkeeping of a gathered buffer that windowed exchanges reuse. dirty / new = (x0, y0, x1, y1, frames): what the
+    last exchange wrote into the peers' slots / what the next one will overwrite. Returns the region the root has to
+    zero first (None when the new region covers the old one)."""
+    if dirty is None:
+        return None
+    covered = new[0] <= dirty[0] and new[1] <= dirty[1] and dirty[2] <= new[2] and dirty[3] <= new[3] and dirty[4] <= new[4]
+    return None if covered else dirty
+
+
+def gather_strips_window(gathered, local, n, window, rows_of, root, send_buf, recv_buf):
+    """gather_strips(root=r) for the first n frames of a batch, moving only the part of every rank's packed strips
+    that can differ from the background: window = (x0, y0, x1, y1), columns [x0, x1) of the image rows [y0, y1)
+    (rt_frame_rect: everything outside is vec3(0) in every rank's strips, so the root's gathered buffer — kept zero
+    there by the caller — already holds it). The root's links carry what the frame's content needs, not W*H*12/world
+    bytes each: at 1 - 4 ranks the full strips of a 1080p frame keep ONE xGMI link busy for longer than the frame takes
+    to render (12.4 MB per frame and link at 2 ranks).
+    local [B, rows, W, 3], gathered [world, B, rows, W, 3]; rows_of[r]: rank r's image rows (strip_rows_of_rank);
+    send_buf / recv_buf: flat staging tensors (recv_buf [world, B*rows*W*3] on the root).
+    Returns the bytes this rank received (root) or sent (peer)."""
+    import torch
+    import torch.distributed as dist
+
+    x0, y0, x1, y1 = window
+    rank, world = dist.get_rank(), dist.get_world_size()
+    gloo = dist.get_backend() == "gloo"
+
+    def piece(r):
+        l0, l1 = rows_in_window(rows_of[r], y0, y1)
+        shape = (n, max(l1 - l0, 0), max(x1 - x0, 0), 3)
+        return l0, l1, shape, shape[0] * shape[1] * shape[2] * 3
+
+    if rank == root:
+        gathered[root].copy_(local)
+        peers = [(r,) + piece(r) for r in range(world) if r != root]
+        peers = [q for q in peers if q[4] > 0]
+        if gloo:
+            for r, l0, l1, shape, cnt in peers:
+                buf = torch.empty(cnt, dtype=local.dtype)
+                dist.recv(buf, src=r)
+                recv_buf[r][:cnt].copy_(buf)
+        elif peers:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, recv_buf[r][:cnt], r) for r, _, _, _, cnt in peers]):
+                w.wait()
+        for r, l0, l1, shape, cnt in peers:
+            gathered[r, :n, l0:l1, x0:x1, :].copy_(recv_buf[r][:cnt].view(shape))
+        return 4 * sum(q[4] for q in peers)
+    l0, l1, shape, cnt = piece(rank)
+    if cnt == 0:
+        return 0
+    out = send_buf[:cnt]
+    out.view(shape).copy_(local[:n, l0:l1, x0:x1, :])
+    if gloo:
+        dist.send(out.cpu() if out.is_cuda else out, dst=root)
+    else:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, root)]):
+            w.wait()
+    return 4 * cnt
+
+
 def new_streams(n: int, high_priority: bool = False):
     """n HIP streams created HERE, one after the other (hipStreamCreateWithFlags through the HIP runtime
     torch already loaded), wrapped for torch. The runtime deals its hardware queues round-robin in creation
@@ -131,7 +196,7 @@ class StripRenderer:
 
     def __init__(self, rt, bvh, cam, features, params, width, height, rank=0, world=1, strip_rows=8,
                  overlap=True, frames_in_flight=1, exchange_always=False,
-                 exchange_batch=1, exchange="allgather"):
+                 exchange_batch=1, exchange="allgather", window=True):
         """frames_in_flight > 1: successive frames go to alternating HIP streams, each with its own
         buffers and library scratch, so the tail of frame k — a few long path trees on an otherwise
         idle chip — overlaps the start of the next frames (with several ranks: the rank's strips of
@@ -145,7 +210,9 @@ class StripRenderer:
         exchanged and assembled; finish() flushes a partial batch.
         exchange_always: take the strips + exchange path with ONE rank too (the all-gather of a
         one-rank group) — how the GPU tests drive the RCCL branch on a one-GPU box.
-        exchange: "allgather" — every rank assembles the frame; "gather" — rank 0 only (gather_strips)."""
+        exchange: "allgather" — every rank assembles the frame; "gather" — rank 0 only (gather_strips).
+        window (gather form with frames in flight): only the part of the strips inside the frames' rt_frame_rect
+        travels (gather_strips_window)."""
         import torch
 
         self.rt, self.bvh, self.cam, self.f, self.p = rt, bvh, cam, features, params
@@ -189,6 +256,21 @@ class StripRenderer:
                 self.rendered = [[torch.cuda.Event() for _ in range(B)] for _ in range(nbuf)]
                 self.consumed = [torch.cuda.Event() for _ in range(nbuf)]
                 self.used = [False] * nbuf
+                # windowed gather: the cameras of each open batch, per-buffer staging, and the region of each
+                # gathered buffer that may be non-zero in the peers' slots (None: nothing)
+                self.window = bool(window) and self.root is not None and world > 1
+                self.batch_cams = [[] for _ in range(nbuf)]
+                self.exchanges = {"plain": 0, "window": 0, "bytes": 0}  # bytes: received (root) / sent (peer)
+                if self.window:
+                    self.rows_of = [strip_rows_of_rank(height, strip_rows, r, world) for r in range(world)]
+                    flat = B * rmax * width * 3
+                    if rank == self.root:
+                        self.recv_buf = [torch.zeros((world, flat), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+                        self.send_buf = [None] * nbuf
+                    else:
+                        self.recv_buf = [None] * nbuf
+                        self.send_buf = [torch.zeros(flat, dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+                    self.dirty = [None] * nbuf
 
     def _render_stream(self, j):
         """Render stream j of the frames in flight; its first use waits for whatever set the scene up."""
@@ -294,6 +376,9 @@ class StripRenderer:
         raw = cur.cuda_stream if self.flight > 1 else stream
         if self.used[i]:
             cur.wait_event(self.consumed[i])  # the exchange that read this buffer last must be over
+        if b == 0:
+            self.batch_cams[i] = []
+        self.batch_cams[i].extend(cams)
         if frames > 1:
             self.rt.render_device_frames(self.bvh, cams, self.f_strips, self.p, self.W, self.H,
                                          self.local[i][b].data_ptr(), rows=self.rows, packed=True,
@@ -313,7 +398,7 @@ class StripRenderer:
         with torch.cuda.stream(self.comm_stream):
             for e in self.rendered[i][:n]:
                 self.comm_stream.wait_event(e)
-            gather_strips(self.gathered[i], self.local[i], self.root)
+            self._gather(i, n)
             raw = self.comm_stream.cuda_stream
             if self.root is None or self.rank == self.root:
                 self.rt.deinterleave_frames(self.gathered[i].data_ptr(), self.out[i].data_ptr(), self.W, self.H,
@@ -324,6 +409,33 @@ class StripRenderer:
             self.consumed[i].record(self.comm_stream)
         self.used[i] = True
         self.frame = self.out[i][n - 1]
+
+    def _gather(self, i, n):
+        """The exchange step proper of batch buffer i (first n frames): whole strips, or — gather form — only the
+        window that the frames' cameras can see anything in (every rank computes the same window from the same
+        cameras; a window of more than 3/4 of the frame goes the plain way)."""
+        if not getattr(self, "window", False):
+            gather_strips(self.gathered[i], self.local[i], self.root)
+            return
+        W, H = self.W, self.H
+        cams = self.batch_cams[i][:n]
+        win = self.rt.frame_rect(self.bvh, cams, self.f_strips, self.p, W, H) if len(cams) == n else (0, 0, W, H)
+        x0, y0, x1, y1 = win
+        plain = (x1 - x0) * (y1 - y0) * 4 > W * H * 3
+        if self.rank == self.root:
+            g, d = self.gathered[i], self.dirty[i]
+            new = (0, 0, W, H, self.batch) if plain else (x0, y0, x1, y1, n)
+            d = stale_region(d, new)
+            if d is not None:
+                g[:, :d[4], :, d[0]:d[2], :].zero_()   # what an earlier, different window left in the peers' slots
+            self.dirty[i] = new
+        self.exchanges["plain" if plain else "window"] += 1
+        if plain:
+            gather_strips(self.gathered[i], self.local[i], self.root)
+            self.exchanges["bytes"] += 4 * self.local[i].numel() * ((self.world - 1) if self.rank == self.root else 1)
+        else:
+            self.exchanges["bytes"] += gather_strips_window(self.gathered[i], self.local[i], n, win, self.rows_of, self.root,
+                                                            self.send_buf[i], self.recv_buf[i])
 
     def finish(self):
         """Flush a partial exchange batch and wait for the device."""

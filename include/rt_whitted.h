@@ -286,6 +286,16 @@ int rt_render_device(const rt_bvh* bvh, const rt_camera* camera, const rt_featur
                      const int32_t* rows, int32_t n_rows, int32_t packed, float* rgb_dev,
                      rt_counters* counters_dev, void* hip_stream);
 
+/* The part of a frame that can differ from the background: rect = {x0, y0, x1, y1} (columns [x0, x1), image rows
+ * — the reference's loop variable y, src/render.cpp:283 — [y0, y1)) such that every pixel outside it is vec3(0)
+ * in the frames rt_render / rt_render_device compute for these cameras (the union over them; before the bloom filter): the rays of those
+ * pixels cannot reach the scene's bounds, and the render calls do not even launch their tiles. Conservative, aligned
+ * outward to 8 pixels; the whole frame when no such statement can be made (depth of field, spheres, a camera inside
+ * the scene's bounds, acceleration structure off). Host arithmetic only. What a multi-GPU host uses to gather only
+ * the part of its strips that carries information (sharding.StripRenderer). */
+int rt_frame_rect(const rt_bvh* bvh, const rt_camera* cameras, int32_t n_cameras, const rt_features* features,
+                  const rt_render_params* params, int32_t width, int32_t height, int32_t rect[4]);
+
 /* -- Several frames (cameras) in ONE launch, framebuffers in HBM: frame k from cameras[k] goes to
  *    rgb_dev + k * frame_stride_floats (0 = tight: rows_per_frame * W * 3 packed, else H * W * 3 row-flipped);
  *    rows / n_rows / packed as in rt_render_device, the same for every frame. What the reference does

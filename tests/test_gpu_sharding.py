@@ -119,3 +119,80 @@ def test_rccl_exchange_branch_on_one_rank(rt, abi, scenes, tmp_path, flight, bat
     want = rt.render(bvh, rt.camera(*scenes.default_camera_args(width, height)), f, p, width, height)
     got = np.load(tmp_path / "frame_nccl.npy")
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _window_rank(rank, world, port, out_dir, width, height, window):
+    """A small object and a moving camera: the windowed gather (only the part of the strips inside rt_frame_rect
+    travels) with windows that shrink and move from batch to batch — every buffer of the exchange is reused with a
+    different window at least once."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    capi = importlib.import_module("computer-graphics-engine_amd.capi")
+    abi = importlib.import_module("computer-graphics-engine_amd.abi")
+    scenes = importlib.import_module("computer-graphics-engine_amd.scenes")
+    sharding = importlib.import_module("computer-graphics-engine_amd.sharding")
+    rt = capi.Library()
+    f = abi.Features.make(**WINDOW_FEATURES)
+    p = abi.RenderParams.make(depth=2)
+    bvh = rt.bvh(rt.scene(scenes.load_fixture_scene("monkey")), f)
+    cams = _window_cams(rt, scenes, width, height)
+    st = torch.cuda.current_stream().cuda_stream
+    r = sharding.StripRenderer(rt, bvh, cams[0], f, p, width, height, rank, world, frames_in_flight=2,
+                               exchange_batch=4, exchange="gather", window=window)
+    saved = 0
+    for k in range(0, len(cams), 2):
+        r.step(st, frames=2, cams=cams[k:k + 2])
+        if (k + 2) % 12 == 0:   # now and then: wait and keep the newest frame
+            r.finish()
+            if rank == 0:
+                np.save(os.path.join(out_dir, f"frame_{saved}.npy"), r.frame.cpu().numpy())
+            saved += 1
+    r.step(st, cams=[cams[5]])   # ends mid-batch
+    r.finish()
+    if rank == 0:
+        np.save(os.path.join(out_dir, f"frame_{saved}.npy"), r.frame.cpu().numpy())
+        np.save(os.path.join(out_dir, "exchanges.npy"), np.array([r.exchanges["plain"], r.exchanges["window"]]))
+    dist.destroy_process_group()
+
+
+WINDOW_FEATURES = dict(enableShading=1, enableHardShadow=1, enableRecursive=1, enableAccelStructure=1)
+
+
+def _window_cams(rt, scenes, width, height):
+    fovy, aspect, look_at, dist_, rot = scenes.default_camera_args(width, height)
+    cams = []
+    for k in range(48):
+        phase = k // 12
+        d = dist_ * (2.0, 4.0, 1.4, 3.0)[phase] + 0.05 * (k % 12)
+        la = (look_at[0] + (0.0, 0.9, 0.0, -0.7)[phase], look_at[1] + (0.0, -0.4, 0.0, 0.5)[phase], look_at[2])
+        cams.append(rt.camera(fovy, aspect, la, d, (rot[0] + 3.0 * k, rot[1] + 7.0 * k, rot[2])))
+    return cams
+
+
+@pytest.mark.parametrize("world,window", [(2, True), (3, True), (2, False)])
+def test_windowed_gather_gives_the_single_rank_frames(rt, abi, scenes, tmp_path, world, window):
+    import torch.multiprocessing as mp
+    width, height = 328, 200
+    port = 29500 + (os.getpid() + 17 * world + (5 if window else 0)) % 90
+    mp.spawn(_window_rank, args=(world, port, str(tmp_path), width, height, window), nprocs=world, join=True)
+    f = abi.Features.make(**WINDOW_FEATURES)
+    p = abi.RenderParams.make(depth=2)
+    bvh = rt.bvh(rt.scene(scenes.load_fixture_scene("monkey")), f)
+    cams = _window_cams(rt, scenes, width, height)
+    rects = [rt.frame_rect(bvh, [c], f, p, width, height) for c in cams]
+    assert len(set(rects)) > 8, "the windows must differ from batch to batch"
+    last = [11, 23, 35, 47, 5]
+    for j, k in enumerate(last):
+        want = rt.render(bvh, cams[k], f, p, width, height)
+        assert (want != 0).any()
+        x0, y0, x1, y1 = rects[k]
+        outside = want.copy()
+        outside[height - y1:height - y0, x0:x1] = 0    # rt_frame_rect's promise, in the row-flipped frame
+        assert not outside.any()
+        got = np.load(tmp_path / f"frame_{j}.npy")
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"frame after pose {k}"
+    plain, windowed = np.load(tmp_path / "exchanges.npy")
+    assert (windowed > 8 and plain <= 2) if window else True

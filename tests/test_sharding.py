@@ -68,3 +68,62 @@ def test_gather_to_root_reassembles_the_frame_on_the_root_only(tmp_path, world, 
         if r != root:  # a peer keeps only its own strips (gathered[r] stays zero elsewhere)
             got = np.load(tmp_path / f"frame_{r}.npy")
             assert not np.array_equal(got, want)
+
+
+def _window_worker(rank, world, height, width, port, out_dir, windows):
+    """B = 2 frames per batch; every rank's packed strips carry a pattern INSIDE the window and zero outside (what
+    rt_frame_rect promises of rendered strips); successive exchanges reuse ONE gathered buffer with different
+    windows, the way StripRenderer does (it zeroes what an earlier window left behind)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root, B = 0, 2
+    rows_of = [sharding.strip_rows_of_rank(height, 8, r, world) for r in range(world)]
+    rmax = sharding.rows_max(height, 8, world)
+    gathered = torch.zeros((world, B, rmax, width, 3), dtype=torch.float32)
+    send = torch.zeros(B * rmax * width * 3, dtype=torch.float32)
+    recv = torch.zeros((world, B * rmax * width * 3), dtype=torch.float32)
+    dirty = None
+    for k, (win, n) in enumerate(windows):
+        x0, y0, x1, y1 = win
+        local = torch.zeros((B, rmax, width, 3), dtype=torch.float32)
+        for b in range(n):
+            for i, y in enumerate(rows_of[rank]):
+                if y0 <= y < y1:
+                    local[b, i, x0:x1] = torch.from_numpy(pattern_row(int(y) + 100 * b + 7 * k, width)[x0:x1])
+        if rank == root:  # StripRenderer._gather's bookkeeping
+            new = (x0, y0, x1, y1, n)
+            d = sharding.stale_region(dirty, new)
+            if d is not None:
+                gathered[:, :d[4], :, d[0]:d[2], :].zero_()
+            dirty = new
+        sharding.gather_strips_window(gathered, local, n, win, rows_of, root, send, recv)
+        if rank == root:
+            for b in range(n):
+                np.save(os.path.join(out_dir, f"frame_{k}_{b}.npy"),
+                        sharding.deinterleave_numpy(gathered[:, b].numpy(), height, 8))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_windowed_gather_moves_only_the_window_and_leaves_no_ghosts(tmp_path, world):
+    """gather_strips_window: windows that shrink, move, touch no strip of some rank, or are empty."""
+    height, width = 76, 40
+    windows = [((8, 16, 32, 64), 2), ((16, 24, 24, 40), 2), ((0, 0, 16, 8), 1), ((24, 60, 40, 76), 2),
+               ((8, 8, 8, 40), 2), ((0, 0, 40, 76), 2), ((32, 40, 40, 48), 1)]
+    port = 29450 + (os.getpid() % 100) + 10 * world
+    mp.spawn(_window_worker, args=(world, height, width, port, str(tmp_path), windows), nprocs=world, join=True)
+    for k, ((x0, y0, x1, y1), n) in enumerate(windows):
+        for b in range(n):
+            want = np.zeros((height, width, 3), np.float32)
+            for y in range(y0, y1):
+                want[height - 1 - y, x0:x1] = pattern_row(y + 100 * b + 7 * k, width)[x0:x1]
+            assert np.array_equal(np.load(tmp_path / f"frame_{k}_{b}.npy"), want), (k, b)
+
+
+def test_rows_in_window():
+    rows = sharding.strip_rows_of_rank(76, 8, 1, 3)   # strips 1, 4, 7: rows 8-15, 32-39, 56-63
+    assert sharding.rows_in_window(rows, 0, 76) == (0, 24)
+    assert sharding.rows_in_window(rows, 10, 34) == (2, 10)
+    assert sharding.rows_in_window(rows, 16, 32) == (8, 8)
+    assert sharding.rows_in_window(rows, 64, 76) == (24, 24)
