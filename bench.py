@@ -111,9 +111,12 @@ def main():
     if args.frames_in_flight is None:
         args.frames_in_flight = 3
     if args.frames_per_launch is None:
-        args.frames_per_launch = 8
+        # a launch should hold about 8 frames' worth of work: a rank's share of a frame is 1 / world of one, and a
+        # launch of less ends in the same ~0.5 ms tail of its longest path trees (tools/share_partition.py: one rank's
+        # share at 8 ranks 0.047 ms per frame with 8 shares per launch, 0.027 with 32)
+        args.frames_per_launch = 8 if world == 1 else min(32, 8 * world)
     if args.exchange_batch is None:
-        args.exchange_batch = 1 if world == 1 else 8
+        args.exchange_batch = 1 if world == 1 else args.frames_per_launch
     # HIP runtime setting, read when the runtime starts: how many hardware queues the streams of this
     # process are dealt over (default 4) = how many of the frames in flight really run side by side
     # (tools/queue_bench.hip); + the exchange stream, torch's RCCL stream and the null stream
@@ -175,6 +178,10 @@ def main():
     if args.tile_log:
         rt.set_option("tile_wlog", args.tile_log[0])
         rt.set_option("tile_hlog", args.tile_log[1])
+    if world > 1 or args.exchange_always:
+        # shares of frames: the launches in flight must really run side by side (the one-launch tile order does not
+        # queue up behind the running trace kernel the way the count / scan / scatter kernels do)
+        rt.set_option("order_one_launch", 2)
     for kv in args.set:
         k_, v_ = kv.split("=")
         rt.set_option(k_, int(v_))
@@ -237,6 +244,7 @@ def main():
         k = first
         for m in launch_sizes(n):
             renderer.step(stream, frames=m, cams=[cams[q % n_poses] for q in range(k, k + m)])
+            renderer.flush()   # several ranks: a launch's frames go to the root while the next launch renders
             k += m
 
     run_frames(-args.warmup, args.warmup)

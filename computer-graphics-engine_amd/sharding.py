@@ -437,14 +437,19 @@ class StripRenderer:
             self.exchanges["bytes"] += gather_strips_window(self.gathered[i], self.local[i], n, win, self.rows_of, self.root,
                                                             self.send_buf[i], self.recv_buf[i])
 
+    def flush(self):
+        """Exchange what the open batch holds now (no host synchronisation); the next frame opens a new batch. A caller
+        that wants every launch's frames on their way as soon as they are rendered calls this after step()."""
+        if self.sharded and self.overlap and self.k % self.batch:
+            n = self.k % self.batch
+            self._exchange((self.k // self.batch) % len(self.local), n)
+            self.k += self.batch - n
+
     def finish(self):
         """Flush a partial exchange batch and wait for the device."""
         import torch
 
-        if self.sharded and self.overlap and self.k % self.batch:
-            n = self.k % self.batch
-            self._exchange((self.k // self.batch) % len(self.local), n)
-            self.k += self.batch - n      # the next frame opens a new batch
+        self.flush()
         torch.cuda.synchronize()
 
     def _log(self, j, frames):
