@@ -148,6 +148,8 @@ struct rt_bvh {
 #ifdef RT_DIAG
     DevBuf<rt::NodePair> diag_nodes;
     DevBuf<rt::LeafRecord> diag_leaf;
+    DevBuf<rt::WideNode> diag_wnodes;
+    DevBuf<rt::LeafRecord> diag_wleaf;
 #endif
     std::mutex mu;
     bool profile = false;
@@ -219,6 +221,7 @@ struct rt_bvh {
 #ifdef RT_DIAG
         v.diag_nodes = diag_nodes.p;
         v.diag_leaf = reinterpret_cast<const float4*>(diag_leaf.p);
+        v.diag_wnodes = diag_wnodes.p, v.diag_wleaf = diag_wleaf.p;
 #endif
         return v;
     }
@@ -872,6 +875,10 @@ int rt_bvh_build(rt_scene* scene, const rt_features* features, rt_bvh** out)
                 memset(&g[i], 0, sizeof(g[i]));
         HIP_TRY(b->wide_leaf.upload(leaf_records(g)));
         HIP_TRY(b->wide_nodes.upload(b->host.wide_nodes));
+#ifdef RT_DIAG
+        HIP_TRY(b->diag_wleaf.upload(leaf_records(g)));
+        HIP_TRY(b->diag_wnodes.upload(b->host.wide_nodes));
+#endif
         HIP_TRY(b->wide_index.upload(b->host.wide_index));
         HIP_TRY(b->wide_ref_leaf.upload(b->host.ref_leaf_of));
         HIP_TRY(b->wide_leaf_box.upload(b->host.wide_leaf_box));
@@ -1526,7 +1533,7 @@ int rt_debug_div_check(uint32_t seed, uint32_t mode, uint64_t n_samples, uint64_
 #ifdef RT_TIMELINE
 constexpr size_t kStampWords = 3u << 17;
 #else
-constexpr size_t kStampWords = 24;
+constexpr size_t kStampWords = 64; // 0..23 exact-topology engine, 32..51 wide engine (rt_wide.h)
 #endif
 int rt_debug_stamps(int reset, unsigned long long* out)
 {

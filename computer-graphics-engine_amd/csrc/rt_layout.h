@@ -187,6 +187,8 @@ struct SceneView {
 #ifdef RT_DIAG // diagnostic builds: second copies at other addresses (tools/diag.sh)
     const NodePair* diag_nodes;
     const float4* diag_leaf;
+    const void* diag_wnodes; // second copies of wide_nodes / wide_leaf
+    const void* diag_wleaf;
 #endif
     uint32_t leaf_flush; // leaf-queue fill at which the wave switches to the leaf phase (tuning, 2..64)
     // the wide tree (rt_wide.h); wide_ok == 0: not built for this scene (spheres, a root that is a leaf, too large)

@@ -573,8 +573,11 @@ RT_DEV void traverse_pair(const SceneView& sv, bool prune, bool want_c, const Ra
     if (wide) {
         uint32_t flush_at = sv.leaf_flush < kWideFlushMax ? sv.leaf_flush : kWideFlushMax;
         WideWalk<Q_MIXED, COUNT> ww { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 128u),
-            make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u), 0u,
-            flush_at < 1u ? 1u : flush_at };
+            make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u),
+#ifdef RT_DIAG
+            make_rsrc(sv.diag_wnodes, sv.wide_n_nodes * 128u), make_rsrc(sv.diag_wleaf, sv.wide_n_groups * 4u * 48u),
+#endif
+            0u, flush_at < 1u ? 1u : flush_at };
         const uint64_t back = ww.run(mine == 1u);
         if (fast_c) {
             const unsigned long long key = L.best[slot_c];

@@ -50,14 +50,25 @@ struct WideWalk {
     LaneCounters& lc;
     uint32_t lane;
     BufRsrc nodes, leaf, index;
+#ifdef RT_DIAG
+    BufRsrc nodes2, leaf2; // second copies (diagnostic builds: tools/ab.py)
+#endif
     uint32_t lq_n = 0; // wave-uniform fill of the leaf queue
     uint32_t flush_at;
+#ifdef RT_STAMPS
+    // diagnostic build: shader-clock sums of this wave's phases (tools/stamps.py)
+    unsigned long long st_steal = 0, st_node = 0, st_leaf = 0, n_node = 0, n_leaf = 0;
+    unsigned long long st_pop = 0, st_load = 0, st_alu = 0, st_push = 0;
+#endif
 
     RT_DEV void flag_fallback(uint32_t r) { atomicOr(&L.wfallback[r >> 5], 1u << (r & 31u)); }
 
     // ---- leaf phase: four lanes per (ray, leaf group) pair, one triangle per lane ------------------------
     RT_DEV void flush_leaves()
     {
+#ifdef RT_STAMPS
+        const unsigned long long tl0 = clock64();
+#endif
         wave_lds_fence();
         for (uint32_t base = 0; base < lq_n; base += 16u) {
             const uint32_t p = base + (lane >> 2), j = lane & 3u;
@@ -76,6 +87,12 @@ struct WideWalk {
                     uint32_t idx = __builtin_amdgcn_raw_buffer_load_b32(index, slot * 4u, 0, 0);
                     const float4 c0 = buf_load16(leaf, off), c1 = buf_load16(leaf, off + 16u), c2 = buf_load16(leaf, off + 32u);
                     asm volatile("" : "+v"(idx));
+#if defined(RT_DIAG) && RT_DIAG == 12 // the same three loads from a second copy of the leaf array
+                    {
+                        const float4 d0 = buf_load16(leaf2, off), d1 = buf_load16(leaf2, off + 16u), d2 = buf_load16(leaf2, off + 32u);
+                        asm volatile("" ::"v"(d0.x), "v"(d1.y), "v"(d2.z));
+                    }
+#endif
                     const float4 a = L.rayA[r];
                     RayL ray;
                     ray.o = mk(a.x, a.y, a.z), ray.d = mk(a.w, rb.x, rb.y);
@@ -95,6 +112,9 @@ struct WideWalk {
             wave_lds_fence();
         }
         lq_n = 0;
+#ifdef RT_STAMPS
+        st_leaf += clock64() - tl0, n_leaf++;
+#endif
     }
 
     // the lanes' hit leaf children (up to four each) appended to the leaf queue: one prefix sum over the lanes'
@@ -131,6 +151,9 @@ struct WideWalk {
         uint32_t touched = 0u; // the dword the previous step requested from this step's node (prefetch)
         const bool prefetch = sv.wide_prefetch != 0u;
         for (;;) {
+#ifdef RT_STAMPS
+            const unsigned long long tn0 = clock64();
+#endif
             if (!have && sp > bot) {
                 sp--;
                 e = L.wstack[sp][lane];
@@ -175,6 +198,10 @@ struct WideWalk {
                     wave_lds_fence();
                 }
             }
+#ifdef RT_STAMPS
+            const unsigned long long tn1 = clock64(); // pop + steal done
+            unsigned long long tn2 = tn1, tn3 = tn1;
+#endif
             bool lf[4] = { false, false, false, false };
             uint32_t ref[4] = { 0u, 0u, 0u, 0u };
             uint32_t r = 0;
@@ -193,7 +220,27 @@ struct WideWalk {
                     const float4 loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
                     const float4 hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
                     const float4 rf = buf_load16(nodes, noff + 96u);
+#if defined(RT_DIAG) && RT_DIAG == 11 // the same seven loads from a second copy of the node array
+                    {
+                        const float4 d0 = buf_load16(nodes2, noff), d1 = buf_load16(nodes2, noff + 16u), d2 = buf_load16(nodes2, noff + 32u);
+                        const float4 d3 = buf_load16(nodes2, noff + 48u), d4 = buf_load16(nodes2, noff + 64u), d5 = buf_load16(nodes2, noff + 80u);
+                        const float4 d6 = buf_load16(nodes2, noff + 96u);
+                        asm volatile("" ::"v"(d0.x), "v"(d1.y), "v"(d2.z), "v"(d3.w), "v"(d4.x), "v"(d5.y), "v"(d6.z));
+                    }
+#endif
+#if defined(RT_DIAG) && RT_DIAG == 14 // the ray-slot reads once more (the neighbouring slot), result unused
+                    {
+                        const uint32_t r2 = r ^ 1u;
+                        const float4 xa = L.rayA[r2], xb = L.rayB[r2], xc = L.rayC[r2];
+                        const unsigned long long xk = L.best[r2];
+                        asm volatile("" ::"v"(xa.x), "v"(xb.y), "v"(xc.z), "v"((uint32_t)xk));
+                    }
+#endif
                     asm volatile("" ::"v"(touched)); // the touch is over by now (loads return in order)
+#ifdef RT_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the stamp after the data has arrived
+                    tn2 = clock64();
+#endif
                     ref[0] = __float_as_uint(rf.x), ref[1] = __float_as_uint(rf.y);
                     ref[2] = __float_as_uint(rf.z), ref[3] = __float_as_uint(rf.w);
                     // t = b * (1/d) - o * (1/d): one FMA per slab plane; s covers its rounding and the box growth rho
@@ -219,12 +266,30 @@ struct WideWalk {
                         lf[k] = hit & wide_is_leaf(ref[k]);
                         in[k] = hit & !wide_is_leaf(ref[k]);
                     }
+#if defined(RT_DIAG) && RT_DIAG == 13 // the four box tests once more (boxes shifted), result unused
+                    {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float tx0 = __builtin_fmaf(bx0[k] + 1.0f, rc.x, -ox), tx1 = __builtin_fmaf(bx1[k] + 1.0f, rc.x, -ox);
+                            const float ty0 = __builtin_fmaf(by0[k] + 1.0f, rc.y, -oy), ty1 = __builtin_fmaf(by1[k] + 1.0f, rc.y, -oy);
+                            const float tz0 = __builtin_fmaf(bz0[k] + 1.0f, rc.z, -oz), tz1 = __builtin_fmaf(bz1[k] + 1.0f, rc.z, -oz);
+                            const float tin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+                            const float tout = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+                            acc += ((tin <= tout + s2) & (tout >= ms) & (tin <= lims)) ? tin : tout;
+                        }
+                        asm volatile("" ::"v"(acc));
+                    }
+#endif
                     if (COUNT) {
                         lc.node_fetch++;
 #pragma unroll
                         for (int k = 0; k < 4; k++)
                             lc.box += ref[k] != kWideEmpty ? 1u : 0u;
                     }
+#ifdef RT_STAMPS
+                    tn3 = clock64();
+#endif
                     // the nearest internal child becomes the current entry, the others are put aside
                     int near = -1;
                     float near_lb = 0.0f;
@@ -260,6 +325,13 @@ struct WideWalk {
                 }
             }
             queue_leaves4(lf, r, ref);
+#ifdef RT_STAMPS
+            {
+                const unsigned long long tn4 = clock64();
+                st_steal += tn1 - tn0, st_load += tn2 - tn1, st_alu += tn3 - tn2, st_push += tn4 - tn3;
+                st_node += tn4 - tn0, n_node++;
+            }
+#endif
             if (lq_n >= flush_at)
                 flush_leaves();
         }
@@ -321,13 +393,37 @@ RT_DEV uint64_t traverse_wide(const SceneView& sv, bool fast, const RayL& ray, c
 {
     uint32_t flush_at = sv.leaf_flush < kWideFlushMax ? sv.leaf_flush : kWideFlushMax;
     WideWalk<MODE, COUNT> w { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 128u),
-        make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u), 0u,
-        flush_at < 1u ? 1u : flush_at };
+        make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u),
+#ifdef RT_DIAG
+        make_rsrc(sv.diag_wnodes, sv.wide_n_nodes * 128u), make_rsrc(sv.diag_wleaf, sv.wide_n_groups * 4u * 48u),
+#endif
+        0u, flush_at < 1u ? 1u : flush_at };
+#ifdef RT_STAMPS
+    const unsigned long long stamp_begin = clock64();
+#endif
     uint64_t back = w.run(fast);
     const unsigned long long key = L.best[lane];
     bool redo = false;
     if (fast && key != kNoHit)
         redo = !wide_winner_stands<COUNT>(sv, ray, inv, key, lc);
+#ifdef RT_STAMPS
+    if (sv.stamps && lane == 0) { // slots 32..: the wide engine (closest / mixed: 32, any hit: 40, node-step split: 48)
+        const unsigned long long total = clock64() - stamp_begin;
+        const int base = MODE == 1 ? 40 : 32;
+        atomicAdd(&sv.stamps[base + 0], w.st_steal);
+        atomicAdd(&sv.stamps[base + 1], w.st_node);
+        atomicAdd(&sv.stamps[base + 2], w.st_leaf);
+        atomicAdd(&sv.stamps[base + 3], total);
+        atomicAdd(&sv.stamps[base + 4], w.n_node);
+        atomicAdd(&sv.stamps[base + 5], w.n_leaf);
+        atomicAdd(&sv.stamps[base + 6], 1ull);
+        atomicMax(&sv.stamps[base + 7], total);
+        atomicAdd(&sv.stamps[48], w.st_load);
+        atomicAdd(&sv.stamps[49], w.st_alu);
+        atomicAdd(&sv.stamps[50], w.st_push);
+        atomicAdd(&sv.stamps[51], w.n_node);
+    }
+#endif
     return back | ballot(redo);
 }
 
