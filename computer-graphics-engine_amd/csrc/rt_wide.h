@@ -119,9 +119,9 @@ struct WideWalk {
 
     // the lanes' hit leaf children (up to four each) appended to the leaf queue: one prefix sum over the lanes'
     // counts (three ballots: the bits of a count 0..4) instead of one ballot + prefix per child
-    RT_DEV void queue_leaves4(const bool lf[4], uint32_t r, const uint32_t ref[4])
+    RT_DEV void queue_leaves4(uint32_t leafm, uint32_t r, const uint32_t ref[4])
     {
-        const uint32_t c = (uint32_t)lf[0] + (uint32_t)lf[1] + (uint32_t)lf[2] + (uint32_t)lf[3];
+        const uint32_t c = (uint32_t)__builtin_popcount(leafm); // leafm: bit k = child k is a hit leaf group
         const uint64_t any = ballot(c != 0u);
         if (any == 0)
             return;
@@ -129,7 +129,7 @@ struct WideWalk {
         uint32_t o = lq_n + prefix_count(b0) + 2u * prefix_count(b1) + 4u * prefix_count(b2);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (lf[k]) { // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
+            if (leafm & (1u << k)) { // ref: bit 31, count - 1 at 30:29, group at 23:0 -> group | (count - 1) << 24 | ray << 26
                 L.wlq[o] = (ref[k] & 0xffffffu) | (((ref[k] >> 29) & 3u) << 24) | (r << 26);
                 o++;
             }
@@ -202,7 +202,7 @@ struct WideWalk {
             const unsigned long long tn1 = clock64(); // pop + steal done
             unsigned long long tn2 = tn1, tn3 = tn1;
 #endif
-            bool lf[4] = { false, false, false, false };
+            uint32_t leafm = 0u; // bit k: child k is a hit leaf group (one VGPR across the step's branches, not four lane masks)
             uint32_t ref[4] = { 0u, 0u, 0u, 0u };
             uint32_t r = 0;
             if (have) {
@@ -250,7 +250,7 @@ struct WideWalk {
                     const float bx0[4] = { lox.x, lox.y, lox.z, lox.w }, bx1[4] = { hix.x, hix.y, hix.z, hix.w };
                     const float by0[4] = { loy.x, loy.y, loy.z, loy.w }, by1[4] = { hiy.x, hiy.y, hiy.z, hiy.w };
                     const float bz0[4] = { loz.x, loz.y, loz.z, loz.w }, bz1[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
-                    bool in[4];
+                    uint32_t inm = 0u; // bit k: child k is a hit internal node
                     float lbk[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -262,9 +262,10 @@ struct WideWalk {
                         // may the ray pass within the slack of the box at a distance in [0, lim]? (positive comparisons:
                         // a NaN — impossible for an all_ok ray and a finite box — would drop the child, never a real one)
                         const bool hit = (tin <= tout + s2) & (tout >= ms) & (tin <= lims) & (ref[k] != kWideEmpty);
-                        lbk[k] = tin - s;
-                        lf[k] = hit & wide_is_leaf(ref[k]);
-                        in[k] = hit & !wide_is_leaf(ref[k]);
+                        lbk[k] = fmaxf(tin - s, 0.0f); // a bound below zero says no more than zero does
+                        const uint32_t hb = hit ? (1u << k) : 0u;
+                        leafm |= wide_is_leaf(ref[k]) ? hb : 0u;
+                        inm |= wide_is_leaf(ref[k]) ? 0u : hb;
                     }
 #if defined(RT_DIAG) && RT_DIAG == 13 // the four box tests once more (boxes shifted), result unused
                     {
@@ -290,25 +291,27 @@ struct WideWalk {
 #ifdef RT_STAMPS
                     tn3 = clock64();
 #endif
-                    // the nearest internal child becomes the current entry, the others are put aside
-                    int near = -1;
-                    float near_lb = 0.0f;
+                    // the nearest internal child becomes the current entry, the others are put aside. Nearest = smallest
+                    // packed key (bound's bits with the child number in the two lowest: non-negative floats order as integers)
+                    uint32_t nkey = 0xffffffffu;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const bool better = in[k] & ((near < 0) | (lbk[k] < near_lb));
-                        near = better ? k : near;
-                        near_lb = better ? lbk[k] : near_lb;
+                        const uint32_t key = (__float_as_uint(lbk[k]) & ~3u) | (uint32_t)k;
+                        nkey = (inm & (1u << k)) ? (key < nkey ? key : nkey) : nkey;
                     }
+                    int near = inm ? (int)(nkey & 3u) : -1;
+                    const float near_lb = __uint_as_float(nkey & ~3u); // the bound, two mantissa bits lower: still a lower bound
                     // room for the (up to three) others? otherwise the exact engine traces this ray — its entries here are
                     // dropped, the result is discarded anyway
-                    if (sp + 3u > kWideStack && ((int)in[0] + (int)in[1] + (int)in[2] + (int)in[3] - (near >= 0 ? 1 : 0)) + (int)sp > (int)kWideStack) {
+                    if (sp + 3u > kWideStack && (uint32_t)__builtin_popcount(inm) - (inm ? 1u : 0u) + sp > kWideStack) {
                         flag_fallback(r);
                         near = -1;
-                        in[0] = in[1] = in[2] = in[3] = false;
+                        inm = 0u;
                     }
+                    const uint32_t pushm = near >= 0 ? inm & ~(1u << near) : 0u;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        if (in[k] & (k != near)) {
+                        if (pushm & (1u << k)) {
                             L.wstack[sp][lane] = (ref[k] << 6) | r;
                             L.wstack_lb[sp][lane] = (uint16_t)lb_to_u16(lbk[k]);
                             sp++;
@@ -324,7 +327,7 @@ struct WideWalk {
                     }
                 }
             }
-            queue_leaves4(lf, r, ref);
+            queue_leaves4(leafm, r, ref);
 #ifdef RT_STAMPS
             {
                 const unsigned long long tn4 = clock64();
