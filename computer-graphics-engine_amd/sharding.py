@@ -5,15 +5,18 @@ The reference's only parallelism is image-space: OpenMP over rows
 independent; scene and BVH are replicated per GPU, 8-row strips are dealt
 round-robin to the ranks (balances an object in the middle of the frame; row
 blocks would not), each rank renders its strips into a packed buffer, ONE
-exchange step — an all-gather of equal-sized packed buffers — assembles them,
-and rt_deinterleave_strips writes the reference's row-flipped frame. The
-area-light RNG is keyed by the global pixel id, so the image does not depend on
-the number of ranks. torch.distributed is plumbing here (backend "nccl" = RCCL
-on ROCm; "gloo" in the CPU tests of the partition logic).
+exchange step per batch of frames assembles them — a gather to rank 0 of the
+part of the strips that can differ from the background (gather_strips_window;
+gather_strips moves whole strips, to the root or — all-gather — to every rank)
+— and rt_deinterleave_strips / rt_deinterleave_frames writes the reference's
+row-flipped frame. The area-light RNG is keyed by the global pixel id, so the
+image does not depend on the number of ranks. torch.distributed is plumbing
+here (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests of the partition
+logic and the one-GPU rehearsals).
 
-Overlap: the exchange of frame k runs on a second HIP stream while frame k+1
-renders (two packed/gathered buffer pairs), so a sequence of frames costs
-max(render, exchange) per frame instead of their sum.
+Overlap: the exchange of one launch's frames runs on a second HIP stream while
+the next launches render, so a sequence of frames costs max(render, exchange)
+per frame instead of their sum.
 """
 from __future__ import annotations
 
