@@ -304,8 +304,16 @@ def main():
             lone.step(stream, cams=[cams[kk]])
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
+        td = []   # the default camera pose (the one round 1's single-pose bench rendered)
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lone.step(stream, cams=[cam])
+            torch.cuda.synchronize()
+            td.append(time.perf_counter() - t0)
         frame_ms_serial = {"mean": round(float(np.mean(ts)) * 1e3, 4), "min": round(min(ts) * 1e3, 4),
                            "max": round(max(ts) * 1e3, 4), "frames": n_serial,
+                           "default_pose": round(float(np.mean(td[1:])) * 1e3, 4),
                            "setting": "one frame per launch, one launch at a time, host-synchronised, 4x4-pixel tiles (the library default)"}
 
     if rank == 0:
