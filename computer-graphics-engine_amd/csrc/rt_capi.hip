@@ -1315,51 +1315,77 @@ int rt_render_sharded(rt_bvh* const* bvhs, int32_t n_shards, const rt_camera* ca
     HIP_TRY(b0->shard_gathered.reserve(shard_floats * (size_t)n_shards));
     HIP_TRY(b0->shard_frame.reserve(frame_floats));
     // ---- every shard: its strips into its packed buffer, then a peer copy into shard 0's gathered buffer ----
+    // an error return must not leave shards in flight behind it: wait for what was enqueued so far
+    int32_t enqueued = 0;
+    auto drain = [&](int code) {
+        for (int32_t q = 0; q < enqueued; q++)
+            if (bvhs[q]->shard_stream) {
+                (void)hipSetDevice(bvhs[q]->scene->device);
+                (void)hipStreamSynchronize(bvhs[q]->shard_stream);
+            }
+        return code;
+    };
+#define SHARD_TRY(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return drain(fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)));       \
+    } while (0)
     for (int32_t s = 0; s < n_shards; s++) {
         rt_bvh* b = bvhs[s];
         const int dev = b->scene->device;
-        HIP_TRY(hipSetDevice(dev));
-        if (dev != dev0) { // peer access both ways, once (an already-enabled pair is not an error here)
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, dev, dev0) == hipSuccess && can)
-                (void)hipDeviceEnablePeerAccess(dev0, 0);
-            (void)hipGetLastError();
+        SHARD_TRY(hipSetDevice(dev));
+        if (!b->shard_stream) {
+            SHARD_TRY(hipStreamCreateWithFlags(&b->shard_stream, hipStreamNonBlocking));
+            if (dev != dev0) {
+                // first use of this shard: peer access dev -> dev0 (the copy below runs on dev's stream) and
+                // dev0 -> dev (shard 0's stream waits on this device's event); ONCE per shard handle, an
+                // already-enabled pair is not an error
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, dev, dev0) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(dev0, 0);
+                can = 0;
+                if (hipSetDevice(dev0) == hipSuccess && hipDeviceCanAccessPeer(&can, dev0, dev) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(dev, 0);
+                (void)hipGetLastError();
+                SHARD_TRY(hipSetDevice(dev));
+            }
         }
-        if (!b->shard_stream)
-            HIP_TRY(hipStreamCreateWithFlags(&b->shard_stream, hipStreamNonBlocking));
         if (!b->shard_done)
-            HIP_TRY(hipEventCreateWithFlags(&b->shard_done, hipEventDisableTiming));
-        HIP_TRY(b->shard_packed.reserve(shard_floats));
+            SHARD_TRY(hipEventCreateWithFlags(&b->shard_done, hipEventDisableTiming));
+        SHARD_TRY(b->shard_packed.reserve(shard_floats));
         std::vector<int32_t> rows;
         for (int32_t k = s; k < n_strips; k += n_shards)
             for (int32_t y = k * strip_rows; y < std::min((k + 1) * strip_rows, height); y++)
                 rows.push_back(y);
+        enqueued = s + 1;
         if (!rows.empty()) {
             rc = rt_render_device(b, camera, &f_strips, params, width, height, rows.data(), (int32_t)rows.size(), 1,
                 b->shard_packed.p, nullptr, b->shard_stream);
             if (rc != RT_OK)
-                return rc;
-            HIP_TRY(hipMemcpyPeerAsync(b0->shard_gathered.p + (size_t)s * shard_floats, dev0, b->shard_packed.p, dev,
+                return drain(rc);
+            SHARD_TRY(hipMemcpyPeerAsync(b0->shard_gathered.p + (size_t)s * shard_floats, dev0, b->shard_packed.p, dev,
                 rows.size() * (size_t)width * 3 * sizeof(float), b->shard_stream));
         }
-        HIP_TRY(hipEventRecord(b->shard_done, b->shard_stream));
+        SHARD_TRY(hipEventRecord(b->shard_done, b->shard_stream));
     }
     // ---- shard 0's device: wait for every shard's copy, de-interleave, filter, hand the frame over ----------
-    HIP_TRY(hipSetDevice(dev0));
+    SHARD_TRY(hipSetDevice(dev0));
     for (int32_t s = 1; s < n_shards; s++)
-        HIP_TRY(hipStreamWaitEvent(b0->shard_stream, bvhs[s]->shard_done, 0));
+        SHARD_TRY(hipStreamWaitEvent(b0->shard_stream, bvhs[s]->shard_done, 0));
     float* frame = rgb_on_device ? rgb : b0->shard_frame.p;
     rt::launch_deinterleave(b0->shard_gathered.p, frame, width, height, strip_rows, n_shards, 1, 1, b0->shard_stream);
-    HIP_TRY(hipGetLastError());
+    SHARD_TRY(hipGetLastError());
     if (features->enableBloomEffect) {
         rc = enqueue_bloom(b0->scratch_for(b0->shard_stream), frame, width, height, *params, b0->shard_stream);
         if (rc != RT_OK)
-            return rc;
+            return drain(rc);
     }
     if (!rgb_on_device)
-        HIP_TRY(hipMemcpyAsync(rgb, frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, b0->shard_stream));
-    HIP_TRY(hipStreamSynchronize(b0->shard_stream));
+        SHARD_TRY(hipMemcpyAsync(rgb, frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, b0->shard_stream));
+    SHARD_TRY(hipStreamSynchronize(b0->shard_stream));
     return RT_OK;
+#undef SHARD_TRY
 }
 
 int rt_render_hits(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features, int32_t width,

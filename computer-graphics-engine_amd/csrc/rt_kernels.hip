@@ -115,6 +115,9 @@ RT_DEV bool tile_pixel(const CameraArgs& c, uint32_t wave, uint32_t lane, int32_
     if (c.super_log == 0) {
         if (c.order) {
             if (c.xcd_order) { // launch position -> the (wave / 8)-th tile of XCD (wave % 8)'s list
+                // the hardware deals WORKGROUPS round-robin to the XCDs: wave index == workgroup index only with
+                // one-wave workgroups (the lists and launch_waves = 8 x the longest list are built on that)
+                static_assert(kBlock == 64, "the XCD-aware tile order assumes one wave per workgroup");
                 const uint32_t xl = wave & 7u, k = wave >> 3;
                 if (k >= c.xcd_count[xl]) {
                     x = y = lrow = 0;

@@ -53,7 +53,7 @@ def deinterleave_numpy(gathered: np.ndarray, height: int, strip_rows: int) -> np
     return frame
 
 
-def gather_strips(gathered, local, root=None):
+def gather_strips(gathered, local, root=None, loopback=False):
     """The ONE exchange step of a frame (or of a batch of frames).
     root = None: every rank's packed strips → every rank (all-gather; every rank ends up with the frame).
     root = r:    → rank r only, as one grouped send / receive per peer (ncclGroupStart … ncclSend / ncclRecv …
@@ -61,7 +61,10 @@ def gather_strips(gathered, local, root=None):
                  peer's buffer, W*H*12/world bytes each, instead of the (world-1)/world of the whole frame that a
                  ring all-gather pushes through EVERY link — at the render rates of this path the frame gather is
                  what limits scaling, so the bench uses this form.
-    RCCL (backend nccl) takes the flat calls; gloo (CPU tests, one-GPU rehearsals) gets list / staged forms."""
+    RCCL (backend nccl) takes the flat calls; gloo (CPU tests, one-GPU rehearsals) gets list / staged forms.
+    loopback (one-rank group, backend nccl): the root is its own peer — its strips travel through the same grouped
+    ncclSend / ncclRecv pair a real peer's would (RCCL accepts a send to self inside a group), so a one-GPU box
+    executes the point-to-point branch of the N-rank run."""
     import torch
     import torch.distributed as dist
 
@@ -73,6 +76,11 @@ def gather_strips(gathered, local, root=None):
             dist.all_gather_into_tensor(gathered, local)
         return
     rank, world = dist.get_rank(), dist.get_world_size()
+    if world == 1 and loopback and not gloo:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, gathered[root], root),
+                                         dist.P2POp(dist.isend, local, root)]):
+            w.wait()
+        return
     if rank == root:
         gathered[root].copy_(local)
     if world == 1:
@@ -111,7 +119,7 @@ def stale_region(dirty, new):
     return None if covered else dirty
 
 
-def gather_strips_window(gathered, local, n, window, rows_of, root, send_buf, recv_buf):
+def gather_strips_window(gathered, local, n, window, rows_of, root, send_buf, recv_buf, loopback=False):
     """gather_strips(root=r) for the first n frames of a batch, moving only the part of every rank's packed strips
     that can differ from the background: window = (x0, y0, x1, y1), columns [x0, x1) of the image rows [y0, y1)
     (rt_frame_rect: everything outside is vec3(0) in every rank's strips, so the root's gathered buffer — kept zero
@@ -120,6 +128,9 @@ def gather_strips_window(gathered, local, n, window, rows_of, root, send_buf, re
     to render (12.4 MB per frame and link at 2 ranks).
     local [B, rows, W, 3], gathered [world, B, rows, W, 3]; rows_of[r]: rank r's image rows (strip_rows_of_rank);
     send_buf / recv_buf: flat staging tensors (recv_buf [world, B*rows*W*3] on the root).
+    loopback (one-rank nccl group): the root's own piece goes through send_buf → grouped send / receive to itself →
+    recv_buf → paste, i.e. the path of a peer's piece (its slot of `gathered` is zeroed first, so the paste is what
+    fills it).
     Returns the bytes this rank received (root) or sent (peer)."""
     import torch
     import torch.distributed as dist
@@ -127,6 +138,20 @@ def gather_strips_window(gathered, local, n, window, rows_of, root, send_buf, re
     x0, y0, x1, y1 = window
     rank, world = dist.get_rank(), dist.get_world_size()
     gloo = dist.get_backend() == "gloo"
+    if world == 1 and loopback and not gloo:
+        l0, l1 = rows_in_window(rows_of[root], y0, y1)
+        shape = (n, max(l1 - l0, 0), max(x1 - x0, 0), 3)
+        cnt = shape[0] * shape[1] * shape[2] * 3
+        gathered[root].zero_()
+        if cnt == 0:
+            return 0
+        out = send_buf[:cnt]
+        out.view(shape).copy_(local[:n, l0:l1, x0:x1, :])
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, recv_buf[root][:cnt], root),
+                                         dist.P2POp(dist.isend, out, root)]):
+            w.wait()
+        gathered[root, :n, l0:l1, x0:x1, :].copy_(recv_buf[root][:cnt].view(shape))
+        return 4 * cnt
 
     def piece(r):
         l0, l1 = rows_in_window(rows_of[r], y0, y1)
@@ -159,6 +184,37 @@ def gather_strips_window(gathered, local, n, window, rows_of, root, send_buf, re
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, root)]):
             w.wait()
     return 4 * cnt
+
+
+def checked_exchange(p2p, gathered, local, n, root):
+    """Run the point-to-point exchange `p2p()` (it fills `gathered` [world, B, rows, W, 3] from every rank's `local`
+    [B, rows, W, 3]) and check it against the all-gather form of the same strips: bitwise over the first n frames, on
+    the root; one all-reduce (MIN) makes the verdict every rank's. Returns None when the exchange stands, else the
+    reason — and then `gathered` holds the all-gather's result on EVERY rank, so the caller can go on with
+    exchange="allgather" from this very batch. An exception out of `p2p` counts as a failed check (a rank stuck
+    inside RCCL cannot be helped from here; the process group's timeout ends such a run)."""
+    import torch
+    import torch.distributed as dist
+
+    why = None
+    try:
+        p2p()
+    except Exception as e:   # noqa: BLE001 — whatever RCCL / torch raises: the all-gather form takes over
+        why = f"{type(e).__name__}: {e}"[:200]
+    ref = torch.zeros_like(gathered)
+    gather_strips(ref, local, None)
+    ok = why is None
+    if ok and dist.get_rank() == root:
+        # outside a window the point-to-point form leaves zeros where the strips ARE zero (rt_frame_rect's promise)
+        ok = bool(torch.equal(gathered[:, :n].view(torch.int32), ref[:, :n].view(torch.int32)))
+        if not ok:
+            why = "the point-to-point gather's strips differ from the all-gather's"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=gathered.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        gathered.copy_(ref)
+        return why or "another rank's point-to-point gather failed its check"
+    return None
 
 
 def new_streams(n: int, high_priority: bool = False):
@@ -199,7 +255,7 @@ class StripRenderer:
 
     def __init__(self, rt, bvh, cam, features, params, width, height, rank=0, world=1, strip_rows=8,
                  overlap=True, frames_in_flight=1, exchange_always=False,
-                 exchange_batch=1, exchange="allgather", window=True):
+                 exchange_batch=1, exchange="allgather", window=True, loopback=False, check_exchange=True):
         """frames_in_flight > 1: successive frames go to alternating HIP streams, each with its own
         buffers and library scratch, so the tail of frame k — a few long path trees on an otherwise
         idle chip — overlaps the start of the next frames (with several ranks: the rank's strips of
@@ -215,16 +271,29 @@ class StripRenderer:
         one-rank group) — how the GPU tests drive the RCCL branch on a one-GPU box.
         exchange: "allgather" — every rank assembles the frame; "gather" — rank 0 only (gather_strips).
         window (gather form with frames in flight): only the part of the strips inside the frames' rt_frame_rect
-        travels (gather_strips_window)."""
+        travels (gather_strips_window).
+        loopback (one rank, backend nccl, gather form): the root is its own peer, so the grouped ncclSend / ncclRecv
+        branch of the N-rank run executes on a one-GPU box.
+        check_exchange: the FIRST point-to-point exchange is checked against the all-gather form of the same
+        strips (bitwise, on the root; the ranks agree on the verdict with one all-reduce); on a mismatch or an
+        exception every rank falls back to exchange="allgather" for the rest of the run (`fallback` says why)."""
+        import ctypes
+
         import torch
+
+        abi = __import__("importlib").import_module("computer-graphics-engine_amd.abi")
 
         self.rt, self.bvh, self.cam, self.f, self.p = rt, bvh, cam, features, params
         self.W, self.H, self.rank, self.world, self.strip_rows = width, height, rank, world, strip_rows
         self.rows = strip_rows_of_rank(height, strip_rows, rank, world)
         self.frame = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
-        self.counters = torch.zeros(16, dtype=torch.int64, device="cuda")
+        # the library memsets and atomically adds sizeof(rt_counters) bytes here: sized from the ABI
+        self.counters = torch.zeros(-(-ctypes.sizeof(abi.Counters) // 8), dtype=torch.int64, device="cuda")
         self.sharded = world > 1 or exchange_always
         self.root = 0 if exchange == "gather" else None   # who assembles the frame (None: every rank)
+        self.loopback = bool(loopback) and world == 1 and self.root is not None
+        self.check_exchange = bool(check_exchange) and self.root is not None and (world > 1 or self.loopback)
+        self.fallback = None   # why the point-to-point gather was given up for the all-gather (None: it was not)
         self.overlap = overlap and self.sharded
         self.k = 0         # frames stepped (several ranks: position in the exchange batches)
         self.launches = 0  # launches issued: launch n goes to render stream n % flight
@@ -261,7 +330,7 @@ class StripRenderer:
                 self.used = [False] * nbuf
                 # windowed gather: the cameras of each open batch, per-buffer staging, and the region of each
                 # gathered buffer that may be non-zero in the peers' slots (None: nothing)
-                self.window = bool(window) and self.root is not None and world > 1
+                self.window = bool(window) and self.root is not None and (world > 1 or self.loopback)
                 self.batch_cams = [[] for _ in range(nbuf)]
                 self.exchanges = {"plain": 0, "window": 0, "bytes": 0}  # bytes: received (root) / sent (peer)
                 if self.window:
@@ -269,7 +338,8 @@ class StripRenderer:
                     flat = B * rmax * width * 3
                     if rank == self.root:
                         self.recv_buf = [torch.zeros((world, flat), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-                        self.send_buf = [None] * nbuf
+                        self.send_buf = [torch.zeros(flat, dtype=torch.float32, device="cuda") if self.loopback else None
+                                         for _ in range(nbuf)]
                     else:
                         self.recv_buf = [None] * nbuf
                         self.send_buf = [torch.zeros(flat, dtype=torch.float32, device="cuda") for _ in range(nbuf)]
@@ -414,11 +484,22 @@ class StripRenderer:
         self.frame = self.out[i][n - 1]
 
     def _gather(self, i, n):
-        """The exchange step proper of batch buffer i (first n frames): whole strips, or — gather form — only the
-        window that the frames' cameras can see anything in (every rank computes the same window from the same
-        cameras; a window of more than 3/4 of the frame goes the plain way)."""
+        """The exchange step proper of batch buffer i (first n frames). The first point-to-point exchange of a run
+        is checked against the all-gather form (check_exchange)."""
+        if not self.check_exchange:
+            self._gather_once(i, n)
+            return
+        self.check_exchange = False
+        why = checked_exchange(lambda: self._gather_once(i, n), self.gathered[i], self.local[i], n, self.root)
+        if why is not None:
+            self.fallback = why
+            self.root, self.window, self.loopback = None, False, False
+
+    def _gather_once(self, i, n):
+        """Whole strips, or — gather form — only the window that the frames' cameras can see anything in (every rank
+        computes the same window from the same cameras; a window of more than 3/4 of the frame goes the plain way)."""
         if not getattr(self, "window", False):
-            gather_strips(self.gathered[i], self.local[i], self.root)
+            gather_strips(self.gathered[i], self.local[i], self.root, loopback=self.loopback)
             return
         W, H = self.W, self.H
         cams = self.batch_cams[i][:n]
@@ -434,11 +515,11 @@ class StripRenderer:
             self.dirty[i] = new
         self.exchanges["plain" if plain else "window"] += 1
         if plain:
-            gather_strips(self.gathered[i], self.local[i], self.root)
-            self.exchanges["bytes"] += 4 * self.local[i].numel() * ((self.world - 1) if self.rank == self.root else 1)
+            gather_strips(self.gathered[i], self.local[i], self.root, loopback=self.loopback)
+            self.exchanges["bytes"] += 4 * self.local[i].numel() * (max(self.world - 1, 1) if self.rank == self.root else 1)
         else:
             self.exchanges["bytes"] += gather_strips_window(self.gathered[i], self.local[i], n, win, self.rows_of, self.root,
-                                                            self.send_buf[i], self.recv_buf[i])
+                                                            self.send_buf[i], self.recv_buf[i], loopback=self.loopback)
 
     def flush(self):
         """Exchange what the open batch holds now (no host synchronisation); the next frame opens a new batch. A caller

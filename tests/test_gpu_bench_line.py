@@ -1,5 +1,6 @@
 """bench.py's one JSON line (the driver's contract): run it as the driver does — a subprocess, a small workload —
-and check the fields the contract names, the roofline / cpu_baseline objects and their internal consistency."""
+and check the fields the contract names, the roofline / cpu_baseline objects and their internal consistency; and
+that `bench.py --gpus N` starts by itself (no launcher), ranks and all."""
 import json
 import os
 import subprocess
@@ -12,39 +13,104 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def run_bench(*args):
+def run_bench(*args, env=None):
+    e = {**os.environ, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", "8"), **(env or {})}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], cwd=ROOT, capture_output=True, text=True,
-                         timeout=900, env={**os.environ, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", "8")})
-    assert out.returncode == 0, out.stderr[-2000:]
+                         timeout=900, env=e)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line on stdout"
     return json.loads(lines[0])
 
 
-def test_bench_line_has_the_contract_fields():
-    steps, warmup = 10, 3
-    d = run_bench("--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--workload", "C2")
+def check_contract(d, steps, warmup, n):
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
-                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+                 ("config", dict)):
         assert isinstance(d[k], t), k
-    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
+    assert d["vs_baseline"] is None and d["n_gpus"] == n and d["steps"] == steps and d["warmup"] == warmup
+    assert d["n_ranks_seen"] == n
     assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["value"] > 0 and d["ms_per_step"] > 0
     c = d["config"]
-    assert c["workload"] == "C2" and "model" not in c
+    assert "model" not in c
     sizes = c["launch_frames"]
     assert (sum(sizes) if isinstance(sizes, list) else sum(int(k) * v for k, v in sizes.items())) == steps
     assert c["rays_bvh_traversed"] + c["rays_culled_before_traversal"] == c["rays_per_frame"]
     # value = rays traced over the timed steps / wall time
     assert abs(d["value"] - c["rays_per_frame"] / d["ms_per_step"] / 1e3) <= 0.02 * d["value"]
+    assert 0 < d["mrays_bvh_traversed"] <= d["value"]
+
+
+def test_bench_line_has_the_contract_fields():
+    steps, warmup = 10, 3
+    d = run_bench("--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--workload", "C2")
+    check_contract(d, steps, warmup, 1)
+    assert d["config"]["workload"] == "C2" and d["workloads"] is None
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
-    # achieved = algorithmic bytes per launch / the launches' average duration
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) <= 0.01 * r["achieved"]
-    assert r["chip_wide"]["launch_overlap"] > 0
+    assert r["kernel"] == "k_trace_level" and r["peak"] > 0 and "traffic" in r
+    a = r["algorithmic"]
+    assert abs(a["rate_gbs"] - a["bytes_per_launch"] / (r["alone"]["launch_us"] * 1e-6) / 1e9) <= 0.01 * a["rate_gbs"]
+    assert r["alone"]["launches"] >= 2 and r["timed"]["launch_overlap"] > 0
     s = d["frame_ms_serial"]
     assert 0 < s["min"] <= s["mean"] <= s["max"] and s["default_pose"] > 0
+    h = d["frame_ms_host_call"]
+    assert 0 < h["min"] <= h["mean"] and h["mean"] >= s["min"] * 0.5
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["value"] > 0 and b["value_1core"] > 0 and b["cores"] >= 1 and b["cpu_model"] and b["sample"]
+
+
+def test_the_drivers_command_every_ceiling_is_a_fraction_and_every_config_has_a_figure():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's line): the roofline's three measured ceilings
+    are <= 1, `bound` names the highest, the alone launch agrees with the committed profile of the same command, and
+    C2 / C4 / C5 carry their own timed figures."""
+    d = run_bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    check_contract(d, 20, 5, 1)
+    assert d["config"]["workload"] == "C3" and d["config"]["resolution"] == [1920, 1080]
+    r = d["roofline"]
+    ceil = r["ceilings"]
+    assert set(ceil) == {"hbm", "l2", "valu_issue", "issue_all"}
+    for name, c in ceil.items():
+        assert 0 < c["frac"] <= 1.0, (name, c)
+        assert abs(c["frac"] - c["achieved"] / c["peak"]) < 2e-3
+    assert r["bound"] == max(ceil, key=lambda k: ceil[k]["frac"])
+    assert r["frac"] == ceil[r["bound"]]["frac"] and r["unit"] == ceil[r["bound"]]["unit"]
+    for k in ("hbm_frac", "l2_frac", "valu_issue_frac", "issue_all_frac"):
+        assert 0 < r["timed"]["chip_wide"][k] <= 1.0, k
+    assert r["traffic"] > 0 and r["alone"]["launches"] >= 2
+    # reproducible: the launch a kernel has to itself takes what it took when the committed profile was made
+    ref = r.get("profile_alone_launch_us")
+    if ref:
+        mine = r["alone"]["launch_us"] * 8.0 / r["alone"]["frames_per_launch"]
+        assert abs(mine - ref) <= 0.05 * ref, (mine, ref)
+    w = d["workloads"]
+    assert set(w) == {"C2", "C4", "C5"}
+    for name, x in w.items():
+        assert x["ms_per_step"] > 0 and x["value"] > 0 and 0 < x["mrays_bvh_traversed"] <= x["value"], name
+        assert x["frame_ms_serial"]["mean"] > 0 and x["steps"] == 20
+    assert w["C5"]["resolution"] == [3840, 2160] and w["C4"]["rays_per_frame"] > w["C2"]["rays_per_frame"]
+
+
+def test_bench_starts_its_own_ranks():
+    """No launcher: `BENCH_REHEARSAL=1 python bench.py --gpus 2` (both ranks on this box's one GPU, gloo carrying the
+    exchange) starts two fresh rank processes, checks its first point-to-point exchange against the all-gather and
+    prints ONE line — what `python bench.py --gpus 8` does on an 8-GPU node over RCCL."""
+    d = run_bench("--gpus", "2", "--steps", "8", "--warmup", "2", "--workload-steps", "4", env={"BENCH_REHEARSAL": "1"})
+    check_contract(d, 8, 2, 2)
+    ex = d["config"]["exchange"]
+    assert ex["form"] == "gather" and ex["fallback"] is None and ex["root_receives_bytes_per_frame"] > 0
+    assert "REHEARSAL" in d["config"]["parallelism"]
+    assert set(d["workloads"]) == {"C4"} and d["workloads"]["C4"]["ms_per_step"] > 0
+
+
+def test_point_to_point_exchange_runs_under_rccl_on_one_rank():
+    """--exchange-always: backend nccl with a one-rank group whose root is its own peer — the grouped ncclSend /
+    ncclRecv + window + paste + de-interleave path of the N-rank run, executed by RCCL on this GPU."""
+    d = run_bench("--gpus", "1", "--steps", "16", "--warmup", "4", "--exchange-always", "--no-cpu-baseline",
+                  "--workload-steps", "0")
+    check_contract(d, 16, 4, 1)
+    ex = d["config"]["exchange"]
+    assert ex["form"] == "gather" and ex["window"] is True and ex["fallback"] is None
+    assert 0 < ex["root_receives_bytes_per_frame"] < 1920 * 1080 * 12

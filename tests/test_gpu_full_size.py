@@ -50,7 +50,7 @@ def test_full_resolution_strips_match_oracle(rt, oracle, scenes, full, cfg_name,
     assert hits_seen > 1000, "the checked strips must cross the object"
 
 
-@pytest.mark.parametrize("cfg_name", ["C3", "C5"])
+@pytest.mark.parametrize("cfg_name", ["C3", "C4", "C5"])
 def test_full_frame_properties(rt, scenes, full, cfg_name):
     c, data, f, p, bvh, ob = full(cfg_name)
     cam = rt.camera(*scenes.default_camera_args(c.width, c.height))

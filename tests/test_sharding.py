@@ -127,3 +127,54 @@ def test_rows_in_window():
     assert sharding.rows_in_window(rows, 10, 34) == (2, 10)
     assert sharding.rows_in_window(rows, 16, 32) == (8, 8)
     assert sharding.rows_in_window(rows, 64, 76) == (24, 24)
+
+
+def _checked_worker(rank, world, port, out_dir, fault):
+    """checked_exchange on B = 2 frames of packed strips: an honest point-to-point gather stands; one that corrupts a
+    value on the root, or raises, is replaced by the all-gather's result on EVERY rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    height, width, B, root = 44, 12, 2, 0
+    rows = sharding.strip_rows_of_rank(height, 8, rank, world)
+    rmax = sharding.rows_max(height, 8, world)
+    local = torch.zeros((B, rmax, width, 3), dtype=torch.float32)
+    for b in range(B):
+        for i, y in enumerate(rows):
+            local[b, i] = torch.from_numpy(pattern_row(int(y) + 100 * b, width))
+    gathered = torch.zeros((world, B, rmax, width, 3), dtype=torch.float32)
+
+    def p2p():
+        if fault == "raise":
+            raise RuntimeError("injected")
+        sharding.gather_strips(gathered, local, root)
+        if fault == "corrupt" and rank == root:
+            gathered[world - 1, 1, 0, 3, 1] += 1.0
+
+    why = sharding.checked_exchange(p2p, gathered, local, B, root)
+    np.save(os.path.join(out_dir, f"g_{rank}.npy"), gathered.numpy())
+    with open(os.path.join(out_dir, f"why_{rank}.txt"), "w") as fh:
+        fh.write(why or "")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fault", [(2, None), (3, "corrupt"), (2, "raise")])
+def test_first_point_to_point_exchange_is_checked_against_the_all_gather(tmp_path, world, fault):
+    port = 29300 + (os.getpid() % 150) + 7 * world + (0 if fault is None else len(fault))
+    mp.spawn(_checked_worker, args=(world, port, str(tmp_path), fault), nprocs=world, join=True)
+    whys = [open(tmp_path / f"why_{r}.txt").read() for r in range(world)]
+    gs = [np.load(tmp_path / f"g_{r}.npy") for r in range(world)]
+    if fault is None:
+        assert whys == [""] * world
+        assert not np.array_equal(gs[1], gs[0])          # only the root holds the strips
+    else:
+        assert all(whys), "every rank falls back, whoever noticed"
+        assert ("differ" in whys[0]) if fault == "corrupt" else ("injected" in whys[0])
+        for r in range(1, world):                        # ... and holds the all-gather's result of THIS batch
+            assert np.array_equal(gs[r], gs[0])
+    # the root's buffer is right either way
+    height, width = 44, 12
+    for b in range(2):
+        frame = sharding.deinterleave_numpy(gs[0][:, b], height, 8)
+        want = np.stack([pattern_row(height - 1 - fy + 100 * b, width) for fy in range(height)])
+        assert np.array_equal(frame, want)
