@@ -29,6 +29,8 @@ std::mutex g_host_call_mu;
 std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
+// rt_set_option("packet", mask): query kinds that take the packet walk of the wide tree (SceneView::packet)
+std::atomic<int> g_packet { 4 }, g_packet_whole { 0 };
 // rt_set_option("wide", 0): traverse the reference-topology tree only (the wide tree stays built)
 std::atomic<int> g_wide { 1 };
 // rt_set_option("xcd_order", 1): the tile dispatch order deals screen blocks to the XCDs (rt_kernels.h CameraArgs)
@@ -217,6 +219,8 @@ struct rt_bvh {
         v.wide_n_ref_leaves = (uint32_t)host.wide_leaf_box.size();
         v.wide_ok = host.wide_ok && g_wide.load() ? 1u : 0u;
         v.wide_prefetch = g_prefetch.load() ? 1u : 0u;
+        v.packet = (uint32_t)g_packet.load();
+        v.packet_whole = g_packet_whole.load() ? 1u : 0u;
         v.stamps = g_stamps;
 #ifdef RT_DIAG
         v.diag_nodes = diag_nodes.p;
@@ -778,6 +782,16 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "prefetch") == 0) {
         g_prefetch.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "packet_whole") == 0) {
+        g_packet_whole.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "packet") == 0) {
+        if (value < 0 || value > 15)
+            return fail(RT_ERR_INVALID, "rt_set_option: packet is a mask of query kinds, 0..15");
+        g_packet.store(value);
         return RT_OK;
     }
     if (name && strcmp(name, "leaf_flush") == 0) {

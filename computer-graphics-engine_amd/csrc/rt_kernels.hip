@@ -389,7 +389,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                         if (need && known >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)known, lc))
                             need = false, by_known = true;
                     }
-                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
+                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl, (sv.packet & 4u) != 0u);
                     if (spos >= 0)
                         known = spos;
                     const int blocked = (spos >= 0 || by_known) ? 1 : 0;
@@ -450,7 +450,8 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                             last_blocker = pa;
                         }
                     } else if (!GENERAL || !(flags & F_TRANSPARENCY)) {
-                        traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
+                        traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl,
+                            (sv.packet & (is_point ? 2u : 4u)) != 0u);
                         if (spos >= 0) {
                             visibility = 0.0f;
                             last_blocker = spos;
@@ -935,7 +936,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     MergeNext mg;
     mg.refl.o = mk(0, 0, 0), mg.refl.d = mk(0, 0, 0);
     // merged traversals (traverse_pair) need a fused launch; they are taken level by level where the rays fit
-    mg.enabled = a.fused != 0u && a.merge_next != 0u;
+    mg.enabled = a.fused != 0u && a.merge_next != 0u && (sv.packet & 2u) == 0u;
     for (;; level++) {
     // ---- closest hit (bvh.intersect, render.cpp:31) — unless the previous level's merged
     //      traversal (MergeNext) already found it
@@ -945,7 +946,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         t = mg.t;
         mg.done = false;
     } else {
-        traverse<Q_CLOSEST, COUNT, LEAN>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
+        traverse<Q_CLOSEST, COUNT, LEAN>(sv, use_bvh, prune, active, ray, t, pos, lc, wl,
+            (sv.packet & ((level == first_level && a.source == SRC_CAMERA) ? 1u : 8u)) != 0u);
     }
     const bool hit = active && pos >= 0;
     if (active) {

@@ -441,9 +441,11 @@ struct Walk {
 // in the reference's own order (bvh.cpp:303-305; sv.leaf_flat).
 // NO_SPHERES: the caller knows the scene holds triangles only (lean kernel variant): the sphere
 // test is not compiled in.
+// packet: the wave's rays are expected to stay together (a tile's primary rays, its shadow rays towards one light
+//   sample): the wide engine walks the tree once for the wave (WideWalk::run_packet). Result-neutral.
 template <int MODE, bool COUNT, bool NO_SPHERES = false>
 RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active, const RayL& ray, float& t,
-    int32_t& pos, LaneCounters& lc, WaveLds& L)
+    int32_t& pos, LaneCounters& lc, WaveLds& L, bool packet = false)
 {
     pos = -1;
     const uint64_t act = ballot(active);
@@ -474,7 +476,7 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
         // The wide engine (rt_wide.h) for the rays it is proven for; the exact-topology engine for the others
         // (zero / tiny / huge / NaN components) and for those the wide engine hands back.
         const bool fast = active && inv.all_ok();
-        const uint64_t back = traverse_wide<MODE, COUNT>(sv, fast, ray, inv, lc, L, lane);
+        const uint64_t back = traverse_wide<MODE, COUNT>(sv, fast, ray, inv, lc, L, lane, packet, t);
         const bool slow = active && (!fast || ((back >> lane) & 1ull) != 0ull);
         if (COUNT && slow)
             lc.exact_rays++;
