@@ -226,6 +226,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
     const uint32_t hits = wave_sum(rc.hits), queued = wave_sum(rc.queued);
     const uint32_t node_fetch = wave_sum(lc.node_fetch), tri_fetch = wave_sum(lc.tri_fetch), grp = wave_sum(lc.grp);
     const uint32_t culled = wave_sum(rc.culled), exact = wave_sum(lc.exact_rays), skipped = wave_sum(rc.skipped);
+    const uint32_t empty = wave_sum(lc.empty_space);
     if (lane == 0) {
         auto add = [](uint64_t* p, uint64_t v) {
             if (v)
@@ -246,6 +247,7 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
         add(&out->group_tests, grp);
         add(&out->rays_culled, culled);
         add(&out->rays_exact, exact);
+        add(&out->rays_empty_space, empty);
     }
 }
 
@@ -389,7 +391,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                         if (need && known >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)known, lc))
                             need = false, by_known = true;
                     }
-                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl, (sv.packet & 4u) != 0u);
+                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
                     if (spos >= 0)
                         known = spos;
                     const int blocked = (spos >= 0 || by_known) ? 1 : 0;
@@ -450,8 +452,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                             last_blocker = pa;
                         }
                     } else if (!GENERAL || !(flags & F_TRANSPARENCY)) {
-                        traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl,
-                            (sv.packet & (is_point ? 2u : 4u)) != 0u);
+                        traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
                         if (spos >= 0) {
                             visibility = 0.0f;
                             last_blocker = spos;
@@ -936,7 +937,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     MergeNext mg;
     mg.refl.o = mk(0, 0, 0), mg.refl.d = mk(0, 0, 0);
     // merged traversals (traverse_pair) need a fused launch; they are taken level by level where the rays fit
-    mg.enabled = a.fused != 0u && a.merge_next != 0u && (sv.packet & 2u) == 0u;
+    mg.enabled = a.fused != 0u && a.merge_next != 0u;
     for (;; level++) {
     // ---- closest hit (bvh.intersect, render.cpp:31) — unless the previous level's merged
     //      traversal (MergeNext) already found it
@@ -946,8 +947,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         t = mg.t;
         mg.done = false;
     } else {
-        traverse<Q_CLOSEST, COUNT, LEAN>(sv, use_bvh, prune, active, ray, t, pos, lc, wl,
-            (sv.packet & ((level == first_level && a.source == SRC_CAMERA) ? 1u : 8u)) != 0u);
+        traverse<Q_CLOSEST, COUNT, LEAN>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
     }
     const bool hit = active && pos >= 0;
     if (active) {

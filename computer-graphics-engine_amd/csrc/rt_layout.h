@@ -199,11 +199,11 @@ struct SceneView {
     const LeafBox* wide_leaf_box;  // per reference leaf
     uint32_t wide_n_nodes, wide_n_groups, wide_n_ref_leaves, wide_ok;
     uint32_t wide_prefetch; // tuning: touch the next node's line at the end of a node step
-    // which kinds of query take the packet walk of the wide tree (rt_wide.h WideWalk::run_packet) instead of the
-    // per-lane walk: bit 0 a tile's primary rays, bit 1 its shadow rays towards a point light, bit 2 its
-    // area-light sample rays, bit 3 reflection rays. Result-neutral (rt_set_option("packet", mask)).
-    uint32_t packet;
-    uint32_t packet_whole; // experiment: the whole walk wave-uniform (run_packet) instead of the shared descent
+    // the occupancy grid (rt_grid.h, host_wide.cpp build_grid); grid_n == 0: none / switched off
+    const uint32_t* grid_bits;
+    uint32_t grid_n;
+    float grid_lo[3], grid_cell[3], grid_inv_cell[3];
+    float grid_smax;
 };
 
 } // namespace rt

@@ -138,266 +138,6 @@ struct WideWalk {
     }
 
 
-    // ---- packet node phase: ONE wave-uniform walk of the tree for all the wave's rays --------------------------
-    // For rays that stay together (a tile's primary rays, its shadow rays towards one light sample): the wave takes
-    // one node, every lane tests ITS OWN ray (slot = lane; the ray's constants stay in registers — no LDS ray table
-    // read, no private deque, no stealing, one node line per step for the whole wave) against the node's four
-    // children with the conservative test of run(), and a child is entered when ANY lane hits it. A stack entry is
-    // (node, mask of the lanes that hit its box); the stack lives in three VGPRs, entry i in lane i. Hit leaf groups
-    // go to the same (ray, group) queue and the same leaf phase as in run(). Which subtrees a ray's triangles are
-    // looked for in is decided by that ray's own tests alone (a lane outside a node's mask never sees its children),
-    // so the set of contenders per ray — and with it the argument at the top of this file — is run()'s.
-    // Closest hit: a lane prunes with min(initial t, its best t so far), refreshed after every leaf phase; children
-    // are entered nearest first as seen by the first lane that hits them. Any hit: a lane leaves the walk as soon
-    // as its slot holds a key. Returns the ray slots whose result must be discarded (stack overflow).
-    RT_DEV uint64_t run_packet(bool seed, const RayL& ray, const RayInv& inv, float t0)
-    {
-        constexpr bool any = MODE == 1;
-        const float rx = inv.y[0], ry = inv.y[1], rz = inv.y[2];
-        const float s = inv.slack * 1.0625f; // as in run(): covers the FMA form's rounding and the box growth rho
-        const float ox = ray.o.x * rx, oy = ray.o.y * ry, oz = ray.o.z * rz;
-        const float s2 = s + s, ms = -s;
-        float lims = t0 + s;
-        bool alive = seed;
-        uint32_t stk_ref = 0u, stk_lo = 0u, stk_hi = 0u, sp = 0u;
-        uint32_t node = 0u;
-        uint64_t mask = ballot(alive), back = 0ull;
-        for (;;) {
-            if (mask == 0ull) { // the next entry that still has a lane to serve
-                const uint64_t live = any ? ballot(alive) : ~0ull;
-                while (sp > 0u && mask == 0ull) {
-                    sp--;
-                    node = read_lane(stk_ref, sp);
-                    mask = (((uint64_t)read_lane(stk_hi, sp) << 32) | (uint64_t)read_lane(stk_lo, sp)) & live;
-                }
-                if (mask == 0ull)
-                    break;
-            }
-#ifdef RT_TIMELINE
-            lc.tl_node_iters++;
-#endif
-            const bool in = ((mask >> lane) & 1ull) != 0ull;
-            const uint32_t noff = node * 128u; // wave-uniform: every lane reads the same line
-            const float4 lox = buf_load16(nodes, noff), loy = buf_load16(nodes, noff + 16u);
-            const float4 loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
-            const float4 hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
-            const float4 rf = buf_load16(nodes, noff + 96u);
-            const uint32_t ref[4] = { uni(__float_as_uint(rf.x)), uni(__float_as_uint(rf.y)), uni(__float_as_uint(rf.z)),
-                uni(__float_as_uint(rf.w)) };
-            const float bx0[4] = { lox.x, lox.y, lox.z, lox.w }, bx1[4] = { hix.x, hix.y, hix.z, hix.w };
-            const float by0[4] = { loy.x, loy.y, loy.z, loy.w }, by1[4] = { hiy.x, hiy.y, hiy.z, hiy.w };
-            const float bz0[4] = { loz.x, loz.y, loz.z, loz.w }, bz1[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
-            uint64_t m[4];
-            bool hit[4];
-            uint32_t tkey[4]; // the child's entry distance as this lane sees it (non-negative float bits order as integers)
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float tx0 = __builtin_fmaf(bx0[k], rx, -ox), tx1 = __builtin_fmaf(bx1[k], rx, -ox);
-                const float ty0 = __builtin_fmaf(by0[k], ry, -oy), ty1 = __builtin_fmaf(by1[k], ry, -oy);
-                const float tz0 = __builtin_fmaf(bz0[k], rz, -oz), tz1 = __builtin_fmaf(bz1[k], rz, -oz);
-                const float tin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
-                const float tout = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-                hit[k] = in & (tin <= tout + s2) & (tout >= ms) & (tin <= lims);
-                tkey[k] = __float_as_uint(fmaxf(tin, 0.0f));
-                m[k] = ref[k] != kWideEmpty ? ballot(hit[k]) : 0ull;
-            }
-            if (COUNT && in) {
-                lc.node_fetch++;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    lc.box += ref[k] != kWideEmpty ? 1u : 0u;
-            }
-            // leaf children: (lane, group) pairs of the lanes that hit them; internal children: the nearest next,
-            // the others on the stack. Everything here is wave-uniform control flow.
-            uint32_t near = 4u, nkey = 0xffffffffu;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (m[k] != 0ull) {
-                    if (wide_is_leaf(ref[k])) {
-                        if (hit[k])
-                            L.wlq[lq_n + prefix_count(m[k])] = (ref[k] & 0xffffffu) | (((ref[k] >> 29) & 3u) << 24) | (lane << 26);
-                        lq_n += (uint32_t)__builtin_popcountll(m[k]);
-                    } else {
-                        const uint32_t key = read_lane(tkey[k], (uint32_t)__builtin_ctzll(m[k]));
-                        if (key < nkey)
-                            nkey = key, near = (uint32_t)k;
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (m[k] != 0ull && !wide_is_leaf(ref[k]) && (uint32_t)k != near) {
-                    if (sp < 64u) {
-                        const bool top = lane == sp; // entry sp lives in lane sp (one compare, three selects)
-                        stk_ref = top ? ref[k] : stk_ref;
-                        stk_lo = top ? (uint32_t)m[k] : stk_lo;
-                        stk_hi = top ? (uint32_t)(m[k] >> 32) : stk_hi;
-                        sp++;
-                    } else {
-                        back |= m[k]; // no room: these rays' results are discarded, the exact engine traces them
-                    }
-                }
-            }
-            mask = 0ull;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (near == (uint32_t)k)
-                    node = ref[k], mask = m[k];
-            if (lq_n >= flush_at) {
-                flush_leaves();
-                const unsigned long long bk = L.best[lane];
-                if (any) {
-                    alive = alive && bk == kNoHit;
-                    mask &= ballot(alive);
-                } else {
-                    const uint32_t t0b = __float_as_uint(t0), bb = (uint32_t)(bk >> 32);
-                    lims = __uint_as_float(t0b < bb ? t0b : bb) + s;
-                }
-            }
-        }
-        if (lq_n)
-            flush_leaves();
-        wave_lds_fence();
-        return back;
-    }
-
-
-    // ---- shared descent: the wave's rays walk down the tree TOGETHER while most of them agree on the way -------
-    // A tile's primary rays, its shadow rays towards one light (sample): before their paths part, every lane of
-    // run() would fetch the same node, make the same choice and push the same far children, step after step, each
-    // step at the full price of the general machinery (pop, steal, ray table, per-lane child selection, the
-    // four-way leaf queue). Here the wave takes ONE node per step, wave-uniform; a lane tests its own ray (slot =
-    // lane, the ray's constants in registers) against the four children exactly as run() does; the wave goes on
-    // into the child most lanes would take next; every lane pushes the other internal children IT hits on its own
-    // deque (what run() would have pushed), hit leaf groups join the leaf queue. The descent ends when fewer than
-    // kTogetherMin lanes follow; run_from() continues from the state the lanes are left in. Which subtrees a ray
-    // enters is decided by its own tests alone, as in run(): only the ORDER of a lane's visits can differ (the
-    // wave's choice of the next child instead of the lane's own nearest), which changes no result.
-    static constexpr uint32_t kTogetherMin = 24u;
-    RT_DEV uint64_t run_together(bool seed, const RayL& ray, const RayInv& inv, float t0)
-    {
-        if (lane < 2u)
-            L.wfallback[lane] = 0u;
-        wave_lds_fence();
-        constexpr bool any = MODE == 1;
-        const float rx = inv.y[0], ry = inv.y[1], rz = inv.y[2];
-        const float s = inv.slack * 1.0625f;
-        const float ox = ray.o.x * rx, oy = ray.o.y * ry, oz = ray.o.z * rz;
-        const float s2 = s + s, ms = -s;
-        float lims = t0 + s;
-        bool in = seed; // this lane still walks with the wave
-        uint32_t sp = 0u, node = 0u;
-        uint32_t e = 0u;
-        float e_lb = 0.0f;
-        bool have = false;
-        uint64_t follow = ballot(in);
-        while ((uint32_t)__builtin_popcountll(follow) >= kTogetherMin) {
-#ifdef RT_TIMELINE
-            lc.tl_node_iters++;
-#endif
-            const uint32_t noff = node * 128u; // wave-uniform: one line for the whole wave
-            const float4 lox = buf_load16(nodes, noff), loy = buf_load16(nodes, noff + 16u);
-            const float4 loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
-            const float4 hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
-            const float4 rf = buf_load16(nodes, noff + 96u);
-            const uint32_t ref[4] = { uni(__float_as_uint(rf.x)), uni(__float_as_uint(rf.y)), uni(__float_as_uint(rf.z)),
-                uni(__float_as_uint(rf.w)) };
-            const float bx0[4] = { lox.x, lox.y, lox.z, lox.w }, bx1[4] = { hix.x, hix.y, hix.z, hix.w };
-            const float by0[4] = { loy.x, loy.y, loy.z, loy.w }, by1[4] = { hiy.x, hiy.y, hiy.z, hiy.w };
-            const float bz0[4] = { loz.x, loz.y, loz.z, loz.w }, bz1[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
-            bool hit[4];
-            float lbk[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float tx0 = __builtin_fmaf(bx0[k], rx, -ox), tx1 = __builtin_fmaf(bx1[k], rx, -ox);
-                const float ty0 = __builtin_fmaf(by0[k], ry, -oy), ty1 = __builtin_fmaf(by1[k], ry, -oy);
-                const float tz0 = __builtin_fmaf(bz0[k], rz, -oz), tz1 = __builtin_fmaf(bz1[k], rz, -oz);
-                const float tin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
-                const float tout = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-                hit[k] = in & (tin <= tout + s2) & (tout >= ms) & (tin <= lims) & (ref[k] != kWideEmpty);
-                lbk[k] = fmaxf(tin - s, 0.0f);
-            }
-            if (COUNT && in) {
-                lc.node_fetch++;
-                lc.grp++; // experiment: lane-level node visits made together
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    lc.box += ref[k] != kWideEmpty ? 1u : 0u;
-            }
-            // this lane's nearest hit internal child (as in run(): packed key = bound's bits | child number)
-            uint32_t nkey = 0xffffffffu;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t key = (__float_as_uint(lbk[k]) & ~3u) | (uint32_t)k;
-                nkey = (hit[k] && !wide_is_leaf(ref[k])) ? (key < nkey ? key : nkey) : nkey;
-            }
-            const uint32_t mine = nkey == 0xffffffffu ? 4u : (nkey & 3u);
-            // the wave goes where most lanes would; leaf children go to the leaf queue
-            uint32_t next = 4u, votes = 0u;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (ref[k] == kWideEmpty)
-                    continue;
-                if (wide_is_leaf(ref[k])) {
-                    const uint64_t m = ballot(hit[k]);
-                    if (m != 0ull) {
-                        if (hit[k])
-                            L.wlq[lq_n + prefix_count(m)] = (ref[k] & 0xffffffu) | (((ref[k] >> 29) & 3u) << 24) | (lane << 26);
-                        lq_n += (uint32_t)__builtin_popcountll(m);
-                    }
-                } else {
-                    const uint32_t v = (uint32_t)__builtin_popcountll(ballot(mine == (uint32_t)k));
-                    if (v > votes)
-                        votes = v, next = (uint32_t)k;
-                }
-            }
-            // every lane puts aside the internal children it hits, except the one the wave enters now
-            bool goes = false;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (ref[k] == kWideEmpty || wide_is_leaf(ref[k]))
-                    continue;
-                if ((uint32_t)k == next) {
-                    goes = hit[k];
-                } else if (hit[k]) {
-                    if (sp < kWideStack) {
-                        L.wstack[sp][lane] = (ref[k] << 6) | lane;
-                        L.wstack_lb[sp][lane] = (uint16_t)lb_to_u16(lbk[k]);
-                        sp++;
-                    } else {
-                        flag_fallback(lane);
-                    }
-                }
-            }
-            in = goes;
-            follow = ballot(in);
-            if (next < 4u) {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (next == (uint32_t)k) {
-                        node = ref[k];
-                        e_lb = lbk[k];
-                    }
-            }
-            if (lq_n >= flush_at) {
-                flush_leaves();
-                const unsigned long long bk = L.best[lane];
-                if (any) {
-                    if (bk != kNoHit)
-                        in = false; // blocked: nothing left to look for (run_from() skips its entries)
-                    follow = ballot(in);
-                } else {
-                    const uint32_t t0b = __float_as_uint(t0), bb = (uint32_t)(bk >> 32);
-                    lims = __uint_as_float(t0b < bb ? t0b : bb) + s;
-                }
-            }
-        }
-        // the lanes still together take the node they stand at as their current entry; everyone goes on alone
-        have = in;
-        e = (node << 6) | lane;
-        return run_from(have, e, e_lb, sp);
-    }
-
     // ---- node phase: private deques + work stealing, as in the exact engine -------------------------------
     // Lanes with `seed` start at the root with their own ray. Returns the mask of ray slots for the exact engine.
     RT_DEV uint64_t run(bool seed)
@@ -405,14 +145,10 @@ struct WideWalk {
         if (lane < 2u)
             L.wfallback[lane] = 0u;
         wave_lds_fence();
-        return run_from(seed, lane /* node 0, ray = lane */, 0.0f, 0u);
-    }
-
-    // The same walk from a given state: the lane's current entry (have, e, e_lb) and the fill sp of its deque
-    // (L.wfallback must have been cleared).
-    RT_DEV uint64_t run_from(bool have, uint32_t e, float e_lb, uint32_t sp)
-    {
-        uint32_t bot = 0;
+        uint32_t bot = 0, sp = 0;
+        bool have = seed;
+        uint32_t e = lane; // node 0, ray = lane
+        float e_lb = 0.0f;
         uint32_t touched = 0u; // the dword the previous step requested from this step's node (prefetch)
         const bool prefetch = sv.wide_prefetch != 0u;
         for (;;) {
@@ -655,11 +391,9 @@ RT_DEV bool wide_known_blocker(const SceneView& sv, const RayL& ray, uint32_t po
 // any hit per slot as MODE says); on return L.best holds their keys, and the returned mask names the slots whose
 // result must be discarded and traced by the exact engine instead. `ray` / `inv`: the lane's own ray (slot = lane).
 // ALL lanes of the wave must call.
-// packet: the rays are expected to stay together — ONE wave-uniform walk (run_packet) instead of the per-lane walk;
-// t0: the lane's limit (its L.rayB[lane].z).
 template <int MODE, bool COUNT>
 RT_DEV uint64_t traverse_wide(const SceneView& sv, bool fast, const RayL& ray, const RayInv& inv, LaneCounters& lc,
-    WaveLds& L, uint32_t lane, bool packet = false, float t0 = 0.0f)
+    WaveLds& L, uint32_t lane)
 {
     uint32_t flush_at = sv.leaf_flush < kWideFlushMax ? sv.leaf_flush : kWideFlushMax;
     WideWalk<MODE, COUNT> w { sv, L, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 128u),
@@ -671,15 +405,7 @@ RT_DEV uint64_t traverse_wide(const SceneView& sv, bool fast, const RayL& ray, c
 #ifdef RT_STAMPS
     const unsigned long long stamp_begin = clock64();
 #endif
-    uint64_t back;
-    if constexpr (MODE != 2) {
-        if (packet)
-            back = sv.packet_whole ? w.run_packet(fast, ray, inv, t0) : w.run_together(fast, ray, inv, t0);
-        else
-            back = w.run(fast);
-    } else {
-        back = w.run(fast);
-    }
+    uint64_t back = w.run(fast);
     const unsigned long long key = L.best[lane];
     bool redo = false;
     if (fast && key != kNoHit)
