@@ -368,7 +368,7 @@ class Bench:
                 alone_ms += [sum(ms_list[q:q + per]) for q in range(0, len(ms_list) - per + 1, per)]
         rt.profile_enable(bvh, False)
 
-        rays_bvh = total["rays"] - total.get("rays_culled", 0) - total.get("rays_empty_space", 0)
+        rays_bvh = total["rays"] - total.get("rays_culled", 0)
         res = {"workload": workload, "cfg": cfg, "data": data, "features": f, "W": W, "H": H, "steps": steps,
                "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "value": total["rays"] / elapsed / 1e6,
                "mrays_bvh": rays_bvh / elapsed / 1e6, "total": total, "mine": mine, "rays_bvh": rays_bvh,
@@ -526,7 +526,6 @@ class Bench:
                 "rays_per_frame": per_frame(total["rays"]),
                 "rays_bvh_traversed": per_frame(res["rays_bvh"]),
                 "rays_culled_before_traversal": per_frame(total.get("rays_culled", 0)),
-                "rays_in_empty_space": per_frame(total.get("rays_empty_space", 0)),
                 "rays_exact_engine": round(total.get("rays_exact", 0) / steps, 2),
                 "rays_shadow_skipped": per_frame(total.get("rays_shadow_skipped", 0)),
                 "rays_reference_equivalent": per_frame(total["rays_ref_equiv"]),

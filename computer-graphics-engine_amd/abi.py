@@ -105,8 +105,7 @@ class RenderParams(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays", "rays_primary", "rays_shadow", "rays_reflect", "rays_ref_equiv", "box_tests", "tri_tests",
-        "sphere_tests", "node_fetches", "tri_fetches", "hits_shaded", "rays_queued", "group_tests", "rays_culled", "rays_shadow_skipped", "rays_exact",
-        "rays_empty_space")]
+        "sphere_tests", "node_fetches", "tri_fetches", "hits_shaded", "rays_queued", "group_tests", "rays_culled", "rays_shadow_skipped", "rays_exact")]
 
     def as_dict(self) -> dict:
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

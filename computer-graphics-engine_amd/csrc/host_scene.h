@@ -66,15 +66,6 @@ struct HostBvh {
     bool wide_ok = false;
     uint32_t wide_depth = 0;
     void build_wide(); // host_wide.cpp; needs records
-    // conservative occupancy grid over the triangles (rt_layout.h OccGrid, rt_grid.h): bit (z * n + y) * n + x is set
-    // when a triangle's bounds, grown by a quarter cell + the largest pruning slack the grid is used with, reach the
-    // voxel. grid_ok false: not built (no wide tree, degenerate bounds).
-    std::vector<uint32_t> grid_bits;
-    uint32_t grid_n = 0;
-    float grid_lo[3] = { 0, 0, 0 }, grid_cell[3] = { 0, 0, 0 };
-    float grid_smax = 0.0f; // rays whose largest |origin| component exceeds this do not use the grid
-    bool grid_ok = false;
-    void build_grid(uint32_t n, float extent); // host_wide.cpp; needs records
     std::string check_wide(uint64_t stats[8]) const; // structural self-check ("" = consistent)
     uint32_t root_ref = 0, root_cnt = 0; // root_cnt: count word (rt_layout.h)
     int num_levels = 0, num_leaves = 0;

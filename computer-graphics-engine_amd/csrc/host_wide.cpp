@@ -236,71 +236,6 @@ void HostBvh::build_wide()
     wide_ok = true;
 }
 
-// The occupancy grid (rt_grid.h): which voxels of an n x n x n grid over the triangles' bounds can hold a candidate's
-// point. A candidate's point lies within rho = 2^-16 x max(|origin|, scene extent) of its triangle (rt_device.h
-// "Pruning"), hence within rho of the triangle's bounds; a voxel is marked when those bounds grown by a quarter cell +
-// rho_max (rho for the largest origin the grid is used with, grid_smax) overlap it. The quarter cell is the room the
-// device's voxel walk needs for its own rounding (rt_grid.h) — four orders of magnitude more than it uses.
-void HostBvh::build_grid(uint32_t n, float extent)
-{
-    grid_ok = false;
-    grid_bits.clear();
-    grid_n = 0;
-    const size_t np = records.size();
-    if (!wide_ok || np == 0 || n < 4u || n > 256u)
-        return;
-    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
-    for (size_t i = 0; i < np; i++) {
-        const PrimRecord& r = records[i];
-        for (int a = 0; a < 3; a++) {
-            lo[a] = std::min(lo[a], (double)std::min(r.v0[a], std::min(r.v1[a], r.v2[a])));
-            hi[a] = std::max(hi[a], (double)std::max(r.v0[a], std::max(r.v1[a], r.v2[a])));
-        }
-    }
-    grid_smax = 64.0f * std::max(extent, 1e-30f);
-    const double rho_max = (double)grid_smax * 1.52587890625e-05; // 2^-16 x grid_smax
-    double cell[3], glo[3], margin[3];
-    for (int a = 0; a < 3; a++) {
-        // the grid box: the bounds grown by the margin on both sides (so that every marked voxel lies inside it)
-        double w = hi[a] - lo[a];
-        const double min_w = std::max((double)extent, 1e-30) * 1e-3; // a flat scene still gets cells of a positive size
-        if (w < min_w)
-            lo[a] -= 0.5 * (min_w - w), hi[a] += 0.5 * (min_w - w), w = min_w;
-        // cell = (w + 2 margin) / n with margin = cell / 4 + rho_max  =>  cell = (w + 2 rho_max) / (n - 0.5)
-        cell[a] = (w + 2.0 * rho_max) / ((double)n - 0.5);
-        margin[a] = 0.25 * cell[a] + rho_max;
-        glo[a] = lo[a] - margin[a];
-        if (!(cell[a] > 0.0) || !std::isfinite(cell[a]) || !std::isfinite(glo[a]))
-            return;
-        grid_lo[a] = (float)glo[a], grid_cell[a] = (float)cell[a];
-        // the device works with these two floats: marking must be conservative for THEM
-        glo[a] = (double)grid_lo[a], cell[a] = (double)grid_cell[a];
-        if (!(grid_cell[a] > 0.0f))
-            return;
-    }
-    grid_bits.assign(((size_t)n * n * n + 31) / 32, 0u);
-    for (size_t i = 0; i < np; i++) {
-        const PrimRecord& r = records[i];
-        int32_t i0[3], i1[3];
-        for (int a = 0; a < 3; a++) {
-            const double tl = (double)std::min(r.v0[a], std::min(r.v1[a], r.v2[a])) - margin[a];
-            const double th = (double)std::max(r.v0[a], std::max(r.v1[a], r.v2[a])) + margin[a];
-            i0[a] = (int32_t)std::floor((tl - glo[a]) / cell[a]);
-            i1[a] = (int32_t)std::floor((th - glo[a]) / cell[a]);
-            i0[a] = std::max(0, std::min((int32_t)n - 1, i0[a]));
-            i1[a] = std::max(0, std::min((int32_t)n - 1, i1[a]));
-        }
-        for (int32_t z = i0[2]; z <= i1[2]; z++)
-            for (int32_t y = i0[1]; y <= i1[1]; y++)
-                for (int32_t x = i0[0]; x <= i1[0]; x++) {
-                    const size_t b = ((size_t)z * n + (size_t)y) * n + (size_t)x;
-                    grid_bits[b >> 5] |= 1u << (b & 31u);
-                }
-    }
-    grid_n = n;
-    grid_ok = true;
-}
-
 // Structural self-check of the wide tree (host only; rt_bvh_wide_check): every triangle of `records` sits in exactly
 // one slot, every child box encloses the bounds of every triangle below it, child words are well-formed.
 // stats: [0] nodes, [1] leaf groups, [2] depth, [3] triangles found, [4] empty child slots, [5] internal children

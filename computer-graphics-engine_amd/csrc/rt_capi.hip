@@ -29,9 +29,6 @@ std::mutex g_host_call_mu;
 std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
-// rt_set_option("grid", 0 / 1): empty-space skipping with the occupancy grid (rt_grid.h); "grid_n": voxels per axis of
-// the grids built by LATER rt_bvh_build calls
-std::atomic<int> g_grid { 1 }, g_grid_n { 64 };
 // rt_set_option("wide", 0): traverse the reference-topology tree only (the wide tree stays built)
 std::atomic<int> g_wide { 1 };
 // rt_set_option("xcd_order", 1): the tile dispatch order deals screen blocks to the XCDs (rt_kernels.h CameraArgs)
@@ -148,7 +145,6 @@ struct rt_bvh {
     DevBuf<rt::LeafRecord> wide_leaf;
     DevBuf<uint32_t> wide_index, wide_ref_leaf;
     DevBuf<rt::LeafBox> wide_leaf_box;
-    DevBuf<uint32_t> grid_bits;
 #ifdef RT_DIAG
     DevBuf<rt::NodePair> diag_nodes;
     DevBuf<rt::LeafRecord> diag_leaf;
@@ -221,14 +217,6 @@ struct rt_bvh {
         v.wide_n_ref_leaves = (uint32_t)host.wide_leaf_box.size();
         v.wide_ok = host.wide_ok && g_wide.load() ? 1u : 0u;
         v.wide_prefetch = g_prefetch.load() ? 1u : 0u;
-        const bool grid_on = host.grid_ok && v.wide_ok != 0u && g_grid.load() != 0;
-        v.grid_bits = grid_on ? grid_bits.p : nullptr;
-        v.grid_n = grid_on ? host.grid_n : 0u;
-        for (int a = 0; a < 3; a++) {
-            v.grid_lo[a] = host.grid_lo[a], v.grid_cell[a] = host.grid_cell[a];
-            v.grid_inv_cell[a] = host.grid_cell[a] > 0.0f ? 1.0f / host.grid_cell[a] : 0.0f;
-        }
-        v.grid_smax = host.grid_smax;
         v.stamps = g_stamps;
 #ifdef RT_DIAG
         v.diag_nodes = diag_nodes.p;
@@ -792,16 +780,6 @@ int rt_set_option(const char* name, int value)
         g_prefetch.store(value != 0);
         return RT_OK;
     }
-    if (name && strcmp(name, "grid") == 0) {
-        g_grid.store(value != 0);
-        return RT_OK;
-    }
-    if (name && strcmp(name, "grid_n") == 0) {
-        if (value != 0 && (value < 4 || value > 256))
-            return fail(RT_ERR_INVALID, "rt_set_option: grid_n must be 0 (no grid) or in [4, 256]");
-        g_grid_n.store(value);
-        return RT_OK;
-    }
     if (name && strcmp(name, "leaf_flush") == 0) {
         if (value < 1 || value > (int)rt::kLeafFlushMax)
             return fail(RT_ERR_INVALID, "rt_set_option: leaf_flush must be in [1, 36]");
@@ -904,9 +882,6 @@ int rt_bvh_build(rt_scene* scene, const rt_features* features, rt_bvh** out)
         HIP_TRY(b->wide_index.upload(b->host.wide_index));
         HIP_TRY(b->wide_ref_leaf.upload(b->host.ref_leaf_of));
         HIP_TRY(b->wide_leaf_box.upload(b->host.wide_leaf_box));
-        b->host.build_grid((uint32_t)g_grid_n.load(), scene->host.extent);
-        if (b->host.grid_ok)
-            HIP_TRY(b->grid_bits.upload(b->host.grid_bits));
     }
 #ifdef RT_DIAG
     HIP_TRY(b->diag_nodes.upload(b->host.pairs));

@@ -226,7 +226,6 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
     const uint32_t hits = wave_sum(rc.hits), queued = wave_sum(rc.queued);
     const uint32_t node_fetch = wave_sum(lc.node_fetch), tri_fetch = wave_sum(lc.tri_fetch), grp = wave_sum(lc.grp);
     const uint32_t culled = wave_sum(rc.culled), exact = wave_sum(lc.exact_rays), skipped = wave_sum(rc.skipped);
-    const uint32_t empty = wave_sum(lc.empty_space);
     if (lane == 0) {
         auto add = [](uint64_t* p, uint64_t v) {
             if (v)
@@ -247,7 +246,6 @@ RT_DEV void flush_counters(rt_counters* out, const LaneCounters& lc, const RayCo
         add(&out->group_tests, grp);
         add(&out->rays_culled, culled);
         add(&out->rays_exact, exact);
-        add(&out->rays_empty_space, empty);
     }
 }
 

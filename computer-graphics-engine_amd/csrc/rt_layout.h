@@ -199,11 +199,6 @@ struct SceneView {
     const LeafBox* wide_leaf_box;  // per reference leaf
     uint32_t wide_n_nodes, wide_n_groups, wide_n_ref_leaves, wide_ok;
     uint32_t wide_prefetch; // tuning: touch the next node's line at the end of a node step
-    // the occupancy grid (rt_grid.h, host_wide.cpp build_grid); grid_n == 0: none / switched off
-    const uint32_t* grid_bits;
-    uint32_t grid_n;
-    float grid_lo[3], grid_cell[3], grid_inv_cell[3];
-    float grid_smax;
 };
 
 } // namespace rt

@@ -20,7 +20,6 @@
 #pragma once
 #include "rt_device.h"
 #include "rt_wide.h"
-#include "rt_grid.h"
 
 namespace rt {
 
@@ -455,24 +454,9 @@ RT_DEV void traverse(const SceneView& sv, bool use_bvh, bool prune, bool active,
 #endif
     const uint32_t lane = lane_id();
     prune = prune && use_bvh && sv.prune_ok != 0u;
-    const RayInv inv = make_ray_inv(ray, sv.extent);
-    // empty-space skipping (rt_grid.h): no candidate lies beyond the last marked voxel the ray passes — the limit
-    // the engines work with is lowered to there; a ray that passes no marked voxel is not traversed at all
-    float t_lim = t;
-    if (use_bvh && sv.root_cnt == 0u && prune && sv.wide_ok != 0u && sv.grid_n != 0u) {
-        if (active) {
-            t_lim = grid_limit(sv, ray, inv, t);
-            if (t_lim < 0.0f) {
-                active = false;
-                if (COUNT)
-                    lc.empty_space++;
-            }
-        }
-        if (ballot(active) == 0)
-            return;
-    }
     L.rayA[lane] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
-    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t_lim, __uint_as_float(inv.guard));
+    const RayInv inv = make_ray_inv(ray, sv.extent);
+    L.rayB[lane] = make_float4(ray.d.y, ray.d.z, t, __uint_as_float(inv.guard));
     L.rayC[lane] = make_float4(inv.y[0], inv.y[1], inv.y[2], inv.slack);
     L.best[lane] = kNoHit;
     Walk<MODE, COUNT> w { sv, L, make_rsrc(use_bvh ? sv.leaf : sv.leaf_flat, sv.n_prims * 48u),
@@ -564,42 +548,20 @@ RT_DEV void traverse_pair(const SceneView& sv, bool prune, bool want_c, const Ra
     prune = prune && sv.prune_ok != 0u;
     const bool wide = prune && sv.wide_ok != 0u;
     const RayInv inv_c = make_ray_inv(ray_c, sv.extent), inv_a = make_ray_inv(ray_a, sv.extent);
-    // empty-space skipping (rt_grid.h), as in traverse()
-    float lim_c = t_c, lim_a = t_a;
-    if (wide && sv.grid_n != 0u) {
-        if (want_c) {
-            lim_c = grid_limit(sv, ray_c, inv_c, t_c);
-            if (lim_c < 0.0f) {
-                want_c = false;
-                if (COUNT)
-                    lc.empty_space++;
-            }
-        }
-        if (want_a) {
-            lim_a = grid_limit(sv, ray_a, inv_a, t_a);
-            if (lim_a < 0.0f) {
-                want_a = false;
-                if (COUNT)
-                    lc.empty_space++;
-            }
-        }
-        if (ballot(want_c || want_a) == 0)
-            return;
-    }
     const bool fast_c = want_c && wide && inv_c.all_ok(), fast_a = want_a && wide && inv_a.all_ok();
     // slot table in L.xfer (free between the engines' runs): 0 empty, 1 wide engine, 2 exact-topology engine
     L.xfer[lane] = 0u;
     wave_lds_fence();
     if (want_c) {
         L.rayA[slot_c] = make_float4(ray_c.o.x, ray_c.o.y, ray_c.o.z, ray_c.d.x);
-        L.rayB[slot_c] = make_float4(ray_c.d.y, ray_c.d.z, lim_c, __uint_as_float(inv_c.guard));
+        L.rayB[slot_c] = make_float4(ray_c.d.y, ray_c.d.z, t_c, __uint_as_float(inv_c.guard));
         L.rayC[slot_c] = make_float4(inv_c.y[0], inv_c.y[1], inv_c.y[2], inv_c.slack);
         L.best[slot_c] = kNoHit;
         L.xfer[slot_c] = fast_c ? 1u : 2u;
     }
     if (want_a) {
         L.rayA[slot_a] = make_float4(ray_a.o.x, ray_a.o.y, ray_a.o.z, ray_a.d.x);
-        L.rayB[slot_a] = make_float4(ray_a.d.y, ray_a.d.z, lim_a, __uint_as_float(inv_a.guard));
+        L.rayB[slot_a] = make_float4(ray_a.d.y, ray_a.d.z, t_a, __uint_as_float(inv_a.guard));
         L.rayC[slot_a] = make_float4(inv_a.y[0], inv_a.y[1], inv_a.y[2], inv_a.slack);
         L.best[slot_a] = kNoHit;
         L.xfer[slot_a] = fast_a ? 1u : 2u;

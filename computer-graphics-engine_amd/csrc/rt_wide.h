@@ -137,7 +137,6 @@ struct WideWalk {
         lq_n += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) + 4u * (uint32_t)__builtin_popcountll(b2);
     }
 
-
     // ---- node phase: private deques + work stealing, as in the exact engine -------------------------------
     // Lanes with `seed` start at the root with their own ray. Returns the mask of ray slots for the exact engine.
     RT_DEV uint64_t run(bool seed)

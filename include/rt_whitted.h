@@ -194,8 +194,6 @@ typedef struct rt_counters {
     uint64_t rays_exact;     /* rays traced by the exact-topology engine: all of them where the wide tree does not
                               * apply (spheres, unpruned policy, brute force, tiny scenes), else the rays that are not
                               * all_ok or that the wide engine handed back (csrc/rt_wide.h) */
-    uint64_t rays_empty_space; /* rays (counted in `rays`) that the occupancy grid proved free of candidates: they pass
-                              * no voxel that holds a triangle, so they are not traversed (csrc/rt_grid.h) */
 } rt_counters;
 
 typedef struct rt_scene rt_scene; /* opaque */
@@ -219,9 +217,7 @@ int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len);
  * "leaf_flush", "min_waves", "super_log", "tile_cull", "launch_rect", "merge_next", "wide" (0: the
  * exact-topology engine alone), "xcd_order" / "xcd_block" (screen blocks of 2^v pixels a side per XCD),
  * "frame_major", "order_one_launch" (the tile order built in one launch: 1 for lone frames, 2 always, 0 never), "skip_unlit"
- * (0: trace the shadow rays of unlit hits too), "prefetch", "grid" (0: no empty-space skipping with the occupancy
- * grid, csrc/rt_grid.h), "grid_n" (voxels per axis of the grids built by later rt_bvh_build calls; 0: none).
- * Unknown names return RT_ERR_INVALID. */
+ * (0: trace the shadow rays of unlit hits too), "prefetch". Unknown names return RT_ERR_INVALID. */
 int rt_set_option(const char* name, int value);
 
 /* Select the HIP device used by subsequent creates on this thread. */

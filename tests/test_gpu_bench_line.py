@@ -38,7 +38,7 @@ def check_contract(d, steps, warmup, n):
     assert "model" not in c
     sizes = c["launch_frames"]
     assert (sum(sizes) if isinstance(sizes, list) else sum(int(k) * v for k, v in sizes.items())) == steps
-    assert abs(c["rays_bvh_traversed"] + c["rays_culled_before_traversal"] + c["rays_in_empty_space"] - c["rays_per_frame"]) <= 2
+    assert c["rays_bvh_traversed"] + c["rays_culled_before_traversal"] == c["rays_per_frame"]
     # value = rays traced over the timed steps / wall time
     assert abs(d["value"] - c["rays_per_frame"] / d["ms_per_step"] / 1e3) <= 0.02 * d["value"]
     assert 0 < d["mrays_bvh_traversed"] <= d["value"]
