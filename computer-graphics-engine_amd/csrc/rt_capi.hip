@@ -29,6 +29,15 @@ std::mutex g_host_call_mu;
 std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
+// rt_set_option("heavy_first", 0 / 1): one-frame launches start the tiles whose waves took longest in the previous
+// frame of the same stream first (TileOrderArgs::cost); 0: rings around the image centre only
+std::atomic<int> g_heavy_first { 1 };
+// rt_set_option("host_bands", n): rt_render into a HOST buffer renders the frame as n bands of rows on alternating
+// streams and copies every band back while the later ones render (1: one launch, then one copy; 0 = automatic:
+// 4 bands where the copy back weighs as much as the render — one ray per pixel, point lights —, 1 where the render
+// dominates and bands would only add launch tails: area lights with soft shadows, several samples per pixel, glossy
+// reflections, transparency)
+std::atomic<int> g_host_bands { 0 };
 // rt_set_option("wide", 0): traverse the reference-topology tree only (the wide tree stays built)
 std::atomic<int> g_wide { 1 };
 // rt_set_option("xcd_order", 1): the tile dispatch order deals screen blocks to the XCDs (rt_kernels.h CameraArgs)
@@ -96,6 +105,12 @@ struct Scratch {
     std::vector<rt::CameraPose> poses; // rt_render_device_frames: the frames' poses of the launch being enqueued
     DevBuf<uint32_t> order; // tile dispatch order (tile_order_for)
     DevBuf<uint32_t> order_rings; // its ring counters
+    // heaviest-first order of lone frames: what every tile's wave took in the previous frame on this stream
+    // (absolute tile coordinates of the full tile grid), the frame shape it belongs to, and whether the cached order
+    // was built from it
+    DevBuf<uint32_t> tile_cost;
+    std::vector<int64_t> cost_sig;
+    bool cost_recorded = false, order_from_cost = false;
     uint32_t xcd_count[8] = {};   // XCD-aware order: lengths of the eight lists of the cached order
     DevBuf<float> samples;   // per-sample colours of multi-sample frames (k_resolve input)
     DevBuf<float> frames;    // k_trace_general: per-wave-slot recursion frames
@@ -158,8 +173,18 @@ struct rt_bvh {
     hipStream_t shard_stream = nullptr;
     hipEvent_t shard_done = nullptr;
     DevBuf<float> shard_packed, shard_gathered, shard_frame;
+    // rt_render into a host buffer: row bands on two render streams, their copies back on a third (host_bands)
+    hipStream_t host_stream[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t host_done[8] = {};
+    DevBuf<float> host_frame;
     ~rt_bvh()
     {
+        for (auto& e : host_done)
+            if (e)
+                (void)hipEventDestroy(e);
+        for (auto& s_ : host_stream)
+            if (s_)
+                (void)hipStreamDestroy(s_);
         if (shard_done)
             (void)hipEventDestroy(shard_done);
         if (shard_stream)
@@ -389,7 +414,8 @@ bool host_launch_rect(const rt_bvh* bvh, rt::CameraArgs& cam)
 // scheduling choice — results do not depend on it.
 // zero / n_zero: words the caller wants cleared on `stream` before its trace launch; *zeroed tells whether the
 // order launch did that on its way.
-int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_t* zero, uint32_t n_zero, bool* zeroed)
+int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_t* zero, uint32_t n_zero, bool* zeroed,
+    bool want_cost = false, uint32_t** cost_out = nullptr, uint32_t* cost_stride_out = nullptr)
 {
     *zeroed = false;
     if (!g_tile_order.load() || cam.super_log != 0)
@@ -409,7 +435,19 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_
     const uint32_t bpl = (uint32_t)g_xcd_block.load();
     const uint32_t bxlog = bpl > cam.tile_wlog ? bpl - cam.tile_wlog : 0u, bylog = bpl > cam.tile_hlog ? bpl - cam.tile_hlog : 0u;
     const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period, xcd, (int64_t)cam.tile_x0, (int64_t)cam.tile_y0, (int64_t)bxlog, (int64_t)bylog, (int64_t)g_frame_major.load(), (int64_t)g_order_one_launch.load() };
-    if (key != sc.order_key || !sc.order.p) {
+    // heaviest first (one-frame launches of whole row ranges): the costs the previous frame of this shape left behind
+    const int64_t full_tx = (cam.vwidth + tw - 1) / tw, full_ty = (cam.n_rows + th - 1) / th;
+    const std::vector<int64_t> sig { (int64_t)cam.vwidth, (int64_t)cam.n_rows, tw, th, (int64_t)cam.row0, cam.rows ? 1 : 0 };
+    const bool cost_ok = want_cost && cam.n_frames <= 1 && !cam.rows && g_heavy_first.load() != 0;
+    if (cost_ok) {
+        if (sc.tile_cost.n < (size_t)(full_tx * full_ty) || sig != sc.cost_sig) {
+            HIP_TRY(sc.tile_cost.reserve((size_t)(full_tx * full_ty)));
+            HIP_TRY(hipMemsetAsync(sc.tile_cost.p, 0, (size_t)(full_tx * full_ty) * sizeof(uint32_t), stream));
+            sc.cost_sig = sig, sc.cost_recorded = false;
+        }
+    }
+    const bool use_cost = cost_ok && sc.cost_recorded;
+    if (key != sc.order_key || !sc.order.p || use_cost != sc.order_from_cost) {
         // built on the device (k_tile_ring_*): the launched grid follows the camera, and a host-built order
         // would put an upload + synchronisation into every launch of a moving camera
         const size_t n = (size_t)(gw * gh);
@@ -456,6 +494,7 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_
         const int one = g_order_one_launch.load();
         o.one_launch = (one == 2 || (one == 1 && o.n_frames == 1)) && keys_per_list <= rt::kTileOrderLdsKeys ? 1u : 0u;
         o.zero = nullptr, o.n_zero = 0;
+        o.cost = use_cost && o.one_launch ? sc.tile_cost.p : nullptr, o.cost_stride = (uint32_t)full_tx; // one-launch form only
         for (uint32_t k = 0, base = 0; k < 8; k++) {
             o.list_base[k] = xcd ? base : 0u;
             base += sc.xcd_count[k];
@@ -465,6 +504,13 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_
         rt::launch_tile_order(o, stream);
         HIP_TRY(hipGetLastError());
         sc.order_key = key;
+        sc.order_from_cost = use_cost;
+    }
+    if (cost_out) { // the trace launch records this frame's costs (the order above was built from the previous ones)
+        *cost_out = cost_ok ? sc.tile_cost.p : nullptr;
+        *cost_stride_out = (uint32_t)full_tx;
+        if (cost_ok)
+            sc.cost_recorded = true;
     }
     cam.xcd_order = (uint32_t)xcd;
     if (xcd) {
@@ -551,6 +597,10 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
         for (int32_t k = 0; k < cam.n_frames && k < rt::kMaxFramesPerLaunch; k++)
             a.poses[k] = sc.poses[(size_t)k];
     }
+    // recursiveRayTrace's branching variants (render.cpp:36-49 transparency chain, :56-99 glossy,
+    // :101-130 non-opaque materials under enableRecursive) run as per-lane state machines (k_trace_general)
+    const bool general = f.enableGlossyReflection || f.enableTransparency
+        || (f.enableRecursive && bvh->scene->host.any_non_opaque);
     if (source == rt::SRC_CAMERA) {
         // the counting pass traces every primary ray; otherwise launch only the tiles that can see the scene
         if (rect) {
@@ -561,7 +611,9 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
         } else {
             a.cam.tile_x0 = a.cam.tile_y0 = a.cam.tiles_w = a.cam.tiles_h = 0;
         }
-        const int rc = tile_order_for(sc, a.cam, stream, sc.counts.p, (uint32_t)n_levels + 1u, &counts_zeroed);
+        a.tile_cost = nullptr, a.cost_stride = 0;
+        const int rc = tile_order_for(sc, a.cam, stream, sc.counts.p, (uint32_t)n_levels + 1u, &counts_zeroed,
+            !counters_dev && fused_from == 0 && !general, &a.tile_cost, &a.cost_stride);
         if (rc != RT_OK)
             return rc;
     }
@@ -572,8 +624,6 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.counters = counters_dev;
     // recursiveRayTrace's branching variants (render.cpp:36-49 transparency chain, :56-99 glossy,
     // :101-130 non-opaque materials under enableRecursive) run as per-lane state machines
-    const bool general = f.enableGlossyReflection || f.enableTransparency
-        || (f.enableRecursive && bvh->scene->host.any_non_opaque);
     if (general) {
         if (f.enableGlossyReflection && (p.rays_per_reflection < 1 || p.rays_per_reflection > 4096 || p.glossy_reflections_cap < 0))
             return fail(RT_ERR_INVALID, "rays_per_reflection must be in [1, 4096], glossy_reflections_cap >= 0");
@@ -778,6 +828,16 @@ int rt_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "prefetch") == 0) {
         g_prefetch.store(value != 0);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "host_bands") == 0) {
+        if (value < 0 || value > 8)
+            return fail(RT_ERR_INVALID, "rt_set_option: host_bands must be in [0, 8] (0 = automatic)");
+        g_host_bands.store(value);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "heavy_first") == 0) {
+        g_heavy_first.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "leaf_flush") == 0) {
@@ -1227,8 +1287,63 @@ int rt_render(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* fe
     if (rc != RT_OK)
         return rc;
     std::lock_guard<std::mutex> g(g_host_call_mu);
-    Scratch& sc = bvh->scratch_for(nullptr);
     const size_t frame_floats = (size_t)width * height * 3;
+    // A frame for the caller's HOST buffer (what renderRayTracing -> Screen asks for): the copy back costs as much
+    // as the render, so the frame goes out as bands of rows on two alternating streams and every band is copied
+    // back (third stream) while the later bands render. Same launches per band as rt_render_device with a row range:
+    // same bits. Not with counters (one counting launch) and not with the whole-frame bloom filter.
+    int32_t n_bands = g_host_bands.load();
+    if (n_bands == 0) {
+        bool heavy = features->enableMultipleRaysPerPixel || features->enableDepthOfField || features->enableGlossyReflection
+            || features->enableTransparency;
+        if (features->enableSoftShadow)
+            for (const rt::LightRec& l : bvh->scene->host.lights)
+                heavy = heavy || l.kind != RT_LIGHT_POINT;
+        n_bands = heavy ? 1 : 4;
+    }
+    if (!counters && !features->enableBloomEffect && n_bands > 1 && row_end - row_begin >= 64 * n_bands) {
+        for (auto& s_ : bvh->host_stream)
+            if (!s_)
+                HIP_TRY(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+        for (int32_t b = 0; b < n_bands; b++)
+            if (!bvh->host_done[b])
+                HIP_TRY(hipEventCreateWithFlags(&bvh->host_done[b], hipEventDisableTiming));
+        HIP_TRY(bvh->host_frame.reserve(frame_floats));
+        int32_t y_edge[9];
+        for (int32_t b = 0; b <= n_bands; b++) // band edges on multiples of 8 rows (tile heights divide 8)
+            y_edge[b] = b == n_bands ? row_end : row_begin + (int32_t)(((int64_t)(row_end - row_begin) * b / n_bands) & ~7ll);
+        auto drain = [&](int code) {
+            for (auto s_ : bvh->host_stream)
+                (void)hipStreamSynchronize(s_);
+            return code;
+        };
+        for (int32_t b = 0; b < n_bands; b++) {
+            hipStream_t s_ = bvh->host_stream[b & 1];
+            Scratch& scb = bvh->scratch_for(s_);
+            rt::CameraArgs cam = camera_args(*camera, width, height);
+            cam.row0 = y_edge[b], cam.n_rows = y_edge[b + 1] - y_edge[b];
+            rt::FoldArgs fold;
+            memset(&fold, 0, sizeof(fold));
+            fold.width = width, fold.height = height, fold.row0 = y_edge[b], fold.packed = 0, fold.rows = nullptr;
+            fold.out = bvh->host_frame.p;
+            rc = enqueue_frame(bvh, scb, *features, *params, cam, fold, false, nullptr, s_);
+            if (rc != RT_OK)
+                return drain(rc);
+            if (hipEventRecord(bvh->host_done[b], s_) != hipSuccess)
+                return drain(fail(RT_ERR_DEVICE, "rt_render: hipEventRecord"));
+        }
+        hipStream_t cs = bvh->host_stream[2];
+        for (int32_t b = 0; b < n_bands; b++) { // rows [y0, y1) occupy flipped rows [H - y1, H - y0)
+            const size_t off = (size_t)(height - y_edge[b + 1]) * width * 3;
+            const size_t bytes = (size_t)(y_edge[b + 1] - y_edge[b]) * width * 3 * sizeof(float);
+            if (hipStreamWaitEvent(cs, bvh->host_done[b], 0) != hipSuccess
+                || hipMemcpyAsync(rgb + off, bvh->host_frame.p + off, bytes, hipMemcpyDeviceToHost, cs) != hipSuccess)
+                return drain(fail(RT_ERR_DEVICE, "rt_render: copy of a band of rows back to the host"));
+        }
+        HIP_TRY(hipStreamSynchronize(cs));
+        return RT_OK;
+    }
+    Scratch& sc = bvh->scratch_for(nullptr);
     HIP_TRY(sc.frame.reserve(frame_floats));
     if (counters)
         HIP_TRY(sc.counters.reserve(1));

@@ -217,7 +217,9 @@ int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len);
  * "leaf_flush", "min_waves", "super_log", "tile_cull", "launch_rect", "merge_next", "wide" (0: the
  * exact-topology engine alone), "xcd_order" / "xcd_block" (screen blocks of 2^v pixels a side per XCD),
  * "frame_major", "order_one_launch" (the tile order built in one launch: 1 for lone frames, 2 always, 0 never), "skip_unlit"
- * (0: trace the shadow rays of unlit hits too), "prefetch". Unknown names return RT_ERR_INVALID. */
+ * (0: trace the shadow rays of unlit hits too), "prefetch", "host_bands" (rt_render into a host buffer: the frame
+ * goes out as that many bands of rows whose copies back overlap the later bands' rendering; 1: one launch and one
+ * copy; 0, the default: 4 for frames as cheap to render as to copy, else 1). Unknown names return RT_ERR_INVALID. */
 int rt_set_option(const char* name, int value);
 
 /* Select the HIP device used by subsequent creates on this thread. */

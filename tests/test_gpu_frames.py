@@ -81,3 +81,33 @@ def test_host_pointer_frames_call(rt, abi, scenes):
     got = rt.render_frames(bvh, cams, f, p, W, H)
     for k, c in enumerate(cams):
         assert np.array_equal(got[k].view(np.uint32), rt.render(bvh, c, f, p, W, H).view(np.uint32)), f"camera {k}"
+
+
+@pytest.mark.parametrize("scene,flags", [
+    ("monkey", dict(enableShading=1, enableHardShadow=1, enableRecursive=1, enableAccelStructure=1)),
+    ("cornell_parallelogram", dict(enableShading=1, enableSoftShadow=1, enableRecursive=1, enableNormalInterp=1,
+                                   enableAccelStructure=1)),
+])
+def test_host_frame_in_bands_of_rows_has_the_bits_of_one_launch(rt, abi, scenes, scene, flags):
+    """rt_render into a HOST buffer (≙ renderRayTracing -> Screen) renders the frame as bands of rows on alternating
+    streams and copies every band back while the later ones render ("host_bands"; default 0 = 4 bands for cheap frames): the bits of the one-launch
+    path (host_bands 1) for whole frames and row ranges, band edges that fall on ragged rows included."""
+    f = abi.Features.make(**flags)
+    p = abi.RenderParams.make(depth=2, parallelogram_n=2, seed=3)
+    bvh = rt.bvh(rt.scene(scenes.load_fixture_scene(scene)), f)
+    W, H = 404, 517                      # neither a multiple of the tile sizes
+    cam = rt.camera(*scenes.default_camera_args(W, H))
+    try:
+        rt.set_option("host_bands", 1)
+        want = rt.render(bvh, cam, f, p, W, H)
+        want_rows = rt.render(bvh, cam, f, p, W, H, rows=(37, 451))
+        assert (want != 0).any()
+        for n in (0, 2, 4, 7):
+            rt.set_option("host_bands", n)
+            for _ in range(2):           # the second call reuses streams, events and the device frame
+                got = rt.render(bvh, cam, f, p, W, H)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
+            got_rows = rt.render(bvh, cam, f, p, W, H, rows=(37, 451))
+            assert np.array_equal(got_rows.view(np.uint32), want_rows.view(np.uint32)), n
+    finally:
+        rt.set_option("host_bands", 0)
