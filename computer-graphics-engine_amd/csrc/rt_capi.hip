@@ -29,9 +29,6 @@ std::mutex g_host_call_mu;
 std::atomic<int> g_unpruned { 0 };
 // rt_set_option("leaf_flush", n): leaf-queue fill that triggers the leaf phase (tuning)
 std::atomic<int> g_leaf_flush { 16 };
-// rt_set_option("heavy_first", 0 / 1): one-frame launches start the tiles whose waves took longest in the previous
-// frame of the same stream first (TileOrderArgs::cost); 0: rings around the image centre only
-std::atomic<int> g_heavy_first { 1 };
 // rt_set_option("host_bands", n): rt_render into a HOST buffer renders the frame as n bands of rows on alternating
 // streams and copies every band back while the later ones render (1: one launch, then one copy; 0 = automatic:
 // 4 bands where the copy back weighs as much as the render — one ray per pixel, point lights —, 1 where the render
@@ -105,12 +102,6 @@ struct Scratch {
     std::vector<rt::CameraPose> poses; // rt_render_device_frames: the frames' poses of the launch being enqueued
     DevBuf<uint32_t> order; // tile dispatch order (tile_order_for)
     DevBuf<uint32_t> order_rings; // its ring counters
-    // heaviest-first order of lone frames: what every tile's wave took in the previous frame on this stream
-    // (absolute tile coordinates of the full tile grid), the frame shape it belongs to, and whether the cached order
-    // was built from it
-    DevBuf<uint32_t> tile_cost;
-    std::vector<int64_t> cost_sig;
-    bool cost_recorded = false, order_from_cost = false;
     uint32_t xcd_count[8] = {};   // XCD-aware order: lengths of the eight lists of the cached order
     DevBuf<float> samples;   // per-sample colours of multi-sample frames (k_resolve input)
     DevBuf<float> frames;    // k_trace_general: per-wave-slot recursion frames
@@ -414,8 +405,7 @@ bool host_launch_rect(const rt_bvh* bvh, rt::CameraArgs& cam)
 // scheduling choice — results do not depend on it.
 // zero / n_zero: words the caller wants cleared on `stream` before its trace launch; *zeroed tells whether the
 // order launch did that on its way.
-int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_t* zero, uint32_t n_zero, bool* zeroed,
-    bool want_cost = false, uint32_t** cost_out = nullptr, uint32_t* cost_stride_out = nullptr)
+int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_t* zero, uint32_t n_zero, bool* zeroed)
 {
     *zeroed = false;
     if (!g_tile_order.load() || cam.super_log != 0)
@@ -435,19 +425,7 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_
     const uint32_t bpl = (uint32_t)g_xcd_block.load();
     const uint32_t bxlog = bpl > cam.tile_wlog ? bpl - cam.tile_wlog : 0u, bylog = bpl > cam.tile_hlog ? bpl - cam.tile_hlog : 0u;
     const std::vector<int64_t> key { gw, gh, tw, th, cx, cy, period, xcd, (int64_t)cam.tile_x0, (int64_t)cam.tile_y0, (int64_t)bxlog, (int64_t)bylog, (int64_t)g_frame_major.load(), (int64_t)g_order_one_launch.load() };
-    // heaviest first (one-frame launches of whole row ranges): the costs the previous frame of this shape left behind
-    const int64_t full_tx = (cam.vwidth + tw - 1) / tw, full_ty = (cam.n_rows + th - 1) / th;
-    const std::vector<int64_t> sig { (int64_t)cam.vwidth, (int64_t)cam.n_rows, tw, th, (int64_t)cam.row0, cam.rows ? 1 : 0 };
-    const bool cost_ok = want_cost && cam.n_frames <= 1 && !cam.rows && g_heavy_first.load() != 0;
-    if (cost_ok) {
-        if (sc.tile_cost.n < (size_t)(full_tx * full_ty) || sig != sc.cost_sig) {
-            HIP_TRY(sc.tile_cost.reserve((size_t)(full_tx * full_ty)));
-            HIP_TRY(hipMemsetAsync(sc.tile_cost.p, 0, (size_t)(full_tx * full_ty) * sizeof(uint32_t), stream));
-            sc.cost_sig = sig, sc.cost_recorded = false;
-        }
-    }
-    const bool use_cost = cost_ok && sc.cost_recorded;
-    if (key != sc.order_key || !sc.order.p || use_cost != sc.order_from_cost) {
+    if (key != sc.order_key || !sc.order.p) {
         // built on the device (k_tile_ring_*): the launched grid follows the camera, and a host-built order
         // would put an upload + synchronisation into every launch of a moving camera
         const size_t n = (size_t)(gw * gh);
@@ -494,7 +472,6 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_
         const int one = g_order_one_launch.load();
         o.one_launch = (one == 2 || (one == 1 && o.n_frames == 1)) && keys_per_list <= rt::kTileOrderLdsKeys ? 1u : 0u;
         o.zero = nullptr, o.n_zero = 0;
-        o.cost = use_cost && o.one_launch ? sc.tile_cost.p : nullptr, o.cost_stride = (uint32_t)full_tx; // one-launch form only
         for (uint32_t k = 0, base = 0; k < 8; k++) {
             o.list_base[k] = xcd ? base : 0u;
             base += sc.xcd_count[k];
@@ -504,13 +481,6 @@ int tile_order_for(Scratch& sc, rt::CameraArgs& cam, hipStream_t stream, uint32_
         rt::launch_tile_order(o, stream);
         HIP_TRY(hipGetLastError());
         sc.order_key = key;
-        sc.order_from_cost = use_cost;
-    }
-    if (cost_out) { // the trace launch records this frame's costs (the order above was built from the previous ones)
-        *cost_out = cost_ok ? sc.tile_cost.p : nullptr;
-        *cost_stride_out = (uint32_t)full_tx;
-        if (cost_ok)
-            sc.cost_recorded = true;
     }
     cam.xcd_order = (uint32_t)xcd;
     if (xcd) {
@@ -611,9 +581,7 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
         } else {
             a.cam.tile_x0 = a.cam.tile_y0 = a.cam.tiles_w = a.cam.tiles_h = 0;
         }
-        a.tile_cost = nullptr, a.cost_stride = 0;
-        const int rc = tile_order_for(sc, a.cam, stream, sc.counts.p, (uint32_t)n_levels + 1u, &counts_zeroed,
-            !counters_dev && fused_from == 0 && !general, &a.tile_cost, &a.cost_stride);
+        const int rc = tile_order_for(sc, a.cam, stream, sc.counts.p, (uint32_t)n_levels + 1u, &counts_zeroed);
         if (rc != RT_OK)
             return rc;
     }
@@ -834,10 +802,6 @@ int rt_set_option(const char* name, int value)
         if (value < 0 || value > 8)
             return fail(RT_ERR_INVALID, "rt_set_option: host_bands must be in [0, 8] (0 = automatic)");
         g_host_bands.store(value);
-        return RT_OK;
-    }
-    if (name && strcmp(name, "heavy_first") == 0) {
-        g_heavy_first.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "leaf_flush") == 0) {

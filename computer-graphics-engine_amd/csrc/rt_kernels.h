@@ -79,10 +79,6 @@ struct LevelArgs {
     uint32_t* state; // per item: bits 0..7 = levels that hit, bit 8 = chain ended on a miss
     uint32_t n_items;
     rt_counters* counters; // NULL unless counting build
-    // one-frame camera launches: what this tile's wave took, in 10 ns ticks, for the next frame's tile order
-    // (TileOrderArgs::cost); NULL: not recorded
-    uint32_t* tile_cost;
-    uint32_t cost_stride;
     // k_trace_general (transparency / glossy recursion): per-lane frame stacks, the extras' parameters
     float* frames;
     int32_t max_frames; // depth + kExtraFrames + 1
@@ -166,12 +162,6 @@ struct TileOrderArgs {
     uint32_t list_base[8]; // first place of list x in `order`
     uint32_t* zero;        // NULL, or n_zero words the launch clears on its way (the level counters of the trace launch)
     uint32_t n_zero;
-    // heaviest first (lone frames): what each tile's wave took in the previous frame of this stream (LevelArgs::
-    // tile_cost, 10 ns ticks; index = absolute tile row * cost_stride + absolute tile column) replaces the ring as the
-    // sort key inside a list — the tiles with the longest path trees start first, so the launch does not end in their
-    // tails. NULL: rings around the image centre. A scheduling choice like every order.
-    const uint32_t* cost;
-    uint32_t cost_stride;
 };
 constexpr uint32_t kTileOrderLdsKeys = 12288; // one-launch form: sort keys per list that fit the LDS (48 KB)
 

@@ -919,27 +919,6 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
 #endif
     if (ballot(active) == 0)
         return;
-    // what this tile's wave takes (100 MHz clock), for the next frame's heaviest-first tile order
-    struct CostEnd {
-        uint32_t* p;
-        unsigned long long t0;
-        __device__ ~CostEnd()
-        {
-            if (p) {
-                const unsigned long long dt = wall_clock64() - t0;
-                *p = dt < 0xffffffffull ? (uint32_t)dt + 1u : 0xffffffffu;
-            }
-        }
-    } cost_end { nullptr, 0ull };
-    if (!MULTI && !COUNT && a.tile_cost && a.source == SRC_CAMERA) {
-        int32_t x, y, lrow;
-        const uint64_t m = ballot(active);
-        const bool ok = tile_pixel(a.cam, wave, (uint32_t)__builtin_ctzll(m), x, y, lrow); // the tile's first pixel
-        if (ok && lane == 0) {
-            cost_end.p = a.tile_cost + ((uint32_t)lrow >> a.cam.tile_hlog) * a.cost_stride + ((uint32_t)x >> a.cam.tile_wlog);
-            cost_end.t0 = wall_clock64();
-        }
-    }
 
     LaneCounters lc;
 #ifdef RT_TIMELINE
@@ -1315,20 +1294,13 @@ __global__ __launch_bounds__(256) void k_div_check(uint32_t seed, uint32_t mode,
 // changes with the camera): rings around the centre of the launched grid, innermost first, as a counting
 // sort — ring sizes (k_tile_ring_count), exclusive scan (k_tile_ring_scan), scatter (k_tile_ring_scatter).
 // The order inside a ring is whatever the atomics give: a scheduling choice, results do not depend on it.
-RT_DEV uint32_t tile_ring(const TileOrderArgs& a, uint32_t tile, uint32_t cost_heavy = 0u)
+RT_DEV uint32_t tile_ring(const TileOrderArgs& a, uint32_t tile)
 {
     const int64_t ty = tile / a.gw, tx = tile - (uint32_t)ty * a.gw;
     const int64_t dx = tx - a.cx, dy = ty % a.period - a.cy;
     const int64_t r = max((dx < 0 ? -dx : dx) * a.tw, (dy < 0 ? -dy : dy) * a.th);
     int64_t q = (r + a.step - 1) / a.step;
     q = q < (int64_t)a.n_rings - 1 ? q : (int64_t)a.n_rings - 1;
-    if (a.cost) { // two classes, rings inside each: the tiles whose waves took at least cost_heavy ticks last time go first
-        const uint32_t c = a.cost[((uint32_t)(ty % a.period) + a.tile_y0) * a.cost_stride + (uint32_t)tx + a.tile_x0];
-        const int64_t half = (int64_t)(a.n_rings / 2u);
-        q = (q >> 1) < half - 1 ? (q >> 1) : half - 1;
-        if (c < cost_heavy)
-            q += half;
-    }
     if (a.xcd_order) // eight lists, one per XCD; in a list frame after frame (a frame's share of the scene fits the
                      // XCD's L2, eight frames' shares do not), each frame centre first
         q += ((int64_t)tile_xcd((uint32_t)tx + a.tile_x0, (uint32_t)(ty % a.period) + a.tile_y0, a.xcd_bxlog, a.xcd_bylog)
@@ -1410,9 +1382,6 @@ __global__ __launch_bounds__(1024) void k_tile_order_lists(const TileOrderArgs a
             a.zero[i] = 0u;
     for (uint32_t i = tid; i < kpl; i += nt)
         hist[i] = 0u;
-    __shared__ uint32_t s_cmax;
-    if (tid == 0)
-        s_cmax = 0u;
     __syncthreads();
     // the list's tiles: in tile row ty the blocks whose column bx has (bx + 3 by) % 8 == list, i.e. every eighth
     const uint32_t gh = a.n_tiles / a.gw;
@@ -1433,25 +1402,10 @@ __global__ __launch_bounds__(1024) void k_tile_order_lists(const TileOrderArgs a
         return atx >= a.tile_x0 && atx < a.tile_x0 + a.gw;
     };
     const uint32_t key0 = a.xcd_order ? list * kpl : 0u;
-    uint32_t heavy = 0u;
-    if (a.cost) { // "heavy" = at least a third of the longest wave of this list's tiles in the previous frame
-        uint32_t m = 0u;
-        for (uint32_t it = tid; it < items; it += nt) {
-            uint32_t tile;
-            if (tile_of(it, tile)) {
-                const uint32_t ty = tile / a.gw, tx = tile - ty * a.gw;
-                const uint32_t c = a.cost[((uint32_t)(ty % (uint32_t)a.period) + a.tile_y0) * a.cost_stride + tx + a.tile_x0];
-                m = c > m ? c : m;
-            }
-        }
-        atomicMax(&s_cmax, m);
-        __syncthreads();
-        heavy = s_cmax / 3u + 1u;
-    }
     for (uint32_t it = tid; it < items; it += nt) {
         uint32_t tile;
         if (tile_of(it, tile)) {
-            const uint32_t k = tile_ring(a, tile, heavy) - key0;
+            const uint32_t k = tile_ring(a, tile) - key0;
             if (k < kpl)
                 atomicAdd(&hist[k], 1u);
         }
@@ -1480,7 +1434,7 @@ __global__ __launch_bounds__(1024) void k_tile_order_lists(const TileOrderArgs a
     for (uint32_t it = tid; it < items; it += nt) {
         uint32_t tile;
         if (tile_of(it, tile)) {
-            const uint32_t k = tile_ring(a, tile, heavy) - key0;
+            const uint32_t k = tile_ring(a, tile) - key0;
             const uint32_t place = k < kpl ? atomicAdd(&hist[k], 1u) : a.n_tiles;
             if (place < a.n_tiles) // holds by construction (the host's list lengths are the lists'); never write outside
                 a.order[place] = tile;

@@ -31,9 +31,6 @@
 //     would overflow. Rare: a ray has to graze the corner of a leaf box for the first, sit on a box face for the second.
 #pragma once
 #include "rt_device.h"
-#ifndef RT_EXP
-#define RT_EXP 0 // experiments on the node step (tools/ab.py builds); 0 = the shipped code
-#endif
 
 namespace rt {
 
@@ -153,9 +150,6 @@ struct WideWalk {
         float e_lb = 0.0f;
         uint32_t touched = 0u; // the dword the previous step requested from this step's node (prefetch)
         const bool prefetch = sv.wide_prefetch != 0u;
-#if RT_EXP == 1
-        uint32_t p_leafm = 0u, p_r = 0u, p_ref[4] = { 0u, 0u, 0u, 0u }; // the previous step's hit leaf groups
-#endif
         for (;;) {
 #ifdef RT_STAMPS
             const unsigned long long tn0 = clock64();
@@ -211,42 +205,6 @@ struct WideWalk {
             uint32_t leafm = 0u; // bit k: child k is a hit leaf group (one VGPR across the step's branches, not four lane masks)
             uint32_t ref[4] = { 0u, 0u, 0u, 0u };
             uint32_t r = 0;
-#if RT_EXP == 1
-            // Software pipelining of the step: the node lines are requested FIRST; the previous step's hit leaf groups
-            // are queued (and a full queue is flushed) while they are on their way; then the box tests. A lane whose
-            // entry turns out to be pruned by a hit the flush just found is caught by `skip` below.
-            bool go = false;
-            float4 lox, loy, loz, hix, hiy, hiz, rf;
-            lox = loy = loz = hix = hiy = hiz = rf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (have) {
-                r = e & 63u;
-                const bool any0 = wide_any_hit_slot<MODE>(r);
-                const unsigned long long bk0 = L.best[r];
-                const uint32_t t0b0 = __float_as_uint(L.rayB[r].z), bb0 = (uint32_t)(bk0 >> 32);
-                const float lim0 = __uint_as_float((any0 || t0b0 < bb0) ? t0b0 : bb0);
-                go = !((any0 & (bk0 != kNoHit)) | (!any0 & (e_lb > lim0)));
-                if (go) {
-                    const uint32_t noff = (e >> 6) * 128u;
-                    lox = buf_load16(nodes, noff), loy = buf_load16(nodes, noff + 16u);
-                    loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
-                    hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
-                    rf = buf_load16(nodes, noff + 96u);
-                }
-            }
-            queue_leaves4(p_leafm, p_r, p_ref);
-            p_leafm = 0u;
-            if (lq_n >= flush_at)
-                flush_leaves();
-            if (have) {
-                have = false;
-                const bool any = wide_any_hit_slot<MODE>(r);
-                const unsigned long long bk = L.best[r];
-                const float4 ra = L.rayA[r], rb = L.rayB[r], rc = L.rayC[r];
-                const uint32_t t0b = __float_as_uint(rb.z), bb = (uint32_t)(bk >> 32);
-                const float lim = __uint_as_float((any || t0b < bb) ? t0b : bb); // shadow rays: t0; else min(t0, best t)
-                const bool skip = !go | (any & (bk != kNoHit)) | (!any & (e_lb > lim));
-                if (!skip) {
-#else
             if (have) {
                 have = false;
                 r = e & 63u;
@@ -262,7 +220,6 @@ struct WideWalk {
                     const float4 loz = buf_load16(nodes, noff + 32u), hix = buf_load16(nodes, noff + 48u);
                     const float4 hiy = buf_load16(nodes, noff + 64u), hiz = buf_load16(nodes, noff + 80u);
                     const float4 rf = buf_load16(nodes, noff + 96u);
-#endif
 #if defined(RT_DIAG) && RT_DIAG == 11 // the same seven loads from a second copy of the node array
                     {
                         const float4 d0 = buf_load16(nodes2, noff), d1 = buf_load16(nodes2, noff + 16u), d2 = buf_load16(nodes2, noff + 32u);
@@ -370,14 +327,7 @@ struct WideWalk {
                     }
                 }
             }
-#if RT_EXP == 1
-            p_leafm = leafm, p_r = r;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                p_ref[k] = ref[k];
-#else
             queue_leaves4(leafm, r, ref);
-#endif
 #ifdef RT_STAMPS
             {
                 const unsigned long long tn4 = clock64();
@@ -385,14 +335,9 @@ struct WideWalk {
                 st_node += tn4 - tn0, n_node++;
             }
 #endif
-#if RT_EXP != 1
             if (lq_n >= flush_at)
                 flush_leaves();
-#endif
         }
-#if RT_EXP == 1
-        queue_leaves4(p_leafm, p_r, p_ref);
-#endif
         if (lq_n)
             flush_leaves();
         wave_lds_fence();
