@@ -1497,65 +1497,6 @@ int rt_render_hits(const rt_bvh* cbvh, const rt_camera* camera, const rt_feature
     return RT_OK;
 }
 
-// Experiment (tools/r3_stream.py): the primary rays of a frame through k_intersect (the tile walk: `tile_log`-sized
-// tiles, one wave each) and through k_stream_hits (the streaming walk, `waves` persistent waves); hit records of
-// both to host memory, kernel milliseconds by HIP events (ms[0] tile walk, ms[1] streaming walk; best of `reps`).
-extern "C" int rt_debug_stream_hits(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* features, int32_t width,
-    int32_t height, int32_t waves, int32_t reps, uint32_t* t_bits_a, int32_t* prim_a, uint32_t* t_bits_b, int32_t* prim_b, double* ms)
-{
-    rt_bvh* bvh = const_cast<rt_bvh*>(cbvh);
-    if (!bvh || !camera || !features || width <= 0 || height <= 0 || waves < 1 || !ms)
-        return fail(RT_ERR_INVALID, "rt_debug_stream_hits: bad argument");
-    std::lock_guard<std::mutex> g(g_host_call_mu);
-    Scratch& sc = bvh->scratch_for(nullptr);
-    const size_t n = (size_t)width * height;
-    HIP_TRY(sc.t_bits.reserve(2 * n));
-    HIP_TRY(sc.prim.reserve(2 * n));
-    HIP_TRY(sc.counts.reserve(512 * 32 + 64));
-    rt::IntersectArgs a;
-    memset(&a, 0, sizeof(a));
-    a.sv = bvh->view();
-    if (!a.sv.wide_ok)
-        return fail(RT_ERR_UNSUPPORTED, "rt_debug_stream_hits: the scene has no wide tree");
-    a.flags = feature_flags(*features);
-    a.source = rt::SRC_CAMERA;
-    a.cam = camera_args(*camera, width, height);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    ms[0] = ms[1] = 1e30;
-    for (int32_t r = 0; r < std::max(1, reps); r++) {
-        float t = 0.0f;
-        a.t_bits = sc.t_bits.p, a.prim = sc.prim.p;
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        rt::launch_intersect(a, false, nullptr);
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-        ms[0] = std::min(ms[0], (double)t);
-        a.t_bits = sc.t_bits.p + n, a.prim = sc.prim.p + n;
-        HIP_TRY(hipMemsetAsync(sc.counts.p, 0, (512 * 32 + 64) * sizeof(uint32_t), nullptr));
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        rt::launch_stream_hits(a, sc.counts.p, (uint32_t)waves, nullptr);
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-        ms[1] = std::min(ms[1], (double)t);
-    }
-    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
-    HIP_TRY(hipMemcpy(ms + 2, sc.counts.p + 512 * 32, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost)); // diagnostic sums (as bit patterns)
-    if (t_bits_a)
-        HIP_TRY(hipMemcpy(t_bits_a, sc.t_bits.p, n * 4, hipMemcpyDeviceToHost));
-    if (prim_a)
-        HIP_TRY(hipMemcpy(prim_a, sc.prim.p, n * 4, hipMemcpyDeviceToHost));
-    if (t_bits_b)
-        HIP_TRY(hipMemcpy(t_bits_b, sc.t_bits.p + n, n * 4, hipMemcpyDeviceToHost));
-    if (prim_b)
-        HIP_TRY(hipMemcpy(prim_b, sc.prim.p + n, n * 4, hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-
 int rt_trace_batch(const rt_bvh* cbvh, const rt_ray* rays, uint32_t n_rays, const uint32_t* pixel_ids,
     const rt_features* features, const rt_render_params* params, float* rgb, rt_counters* counters)
 {

@@ -120,7 +120,6 @@ struct LaneCounters {
     uint32_t grp = 0;                       // lane-level group-box tests (leaf phase)
     uint32_t node_fetch = 0, tri_fetch = 0; // lane-level record fetches (64 B / 96 B each)
     uint32_t exact_rays = 0;                // rays this lane's slot sent through the exact-topology engine
-    uint32_t empty_ticks_node = 0, empty_ticks_flush = 0, empty_ticks_total = 0; // streaming-walk diagnostic
 #ifdef RT_TIMELINE
     uint32_t tl_node_iters = 0, tl_leaf_steps = 0, tl_traversals = 0; // wave-uniform step counts (diagnostic)
 #endif

@@ -178,7 +178,6 @@ void launch_fold(const FoldArgs& a, hipStream_t s);
 void launch_resolve(const ResolveArgs& a, hipStream_t s);
 void launch_bloom(const BloomArgs& a, hipStream_t s);
 void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s);
-void launch_stream_hits(const IntersectArgs& a, uint32_t* counter, uint32_t waves, hipStream_t s); // experiment
 void launch_div_check(uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t per_thread, unsigned long long* out,
     hipStream_t s);
 void launch_deinterleave(const float* gathered, float* frames, int32_t width, int32_t height, int32_t strip_rows,

@@ -19,7 +19,6 @@
 // the other, which the fold reproduces as (direct + r) + r.
 #include "rt_kernels.h"
 #include "rt_shade.h"
-#include "rt_stream.h"
 
 namespace rt {
 
@@ -1022,142 +1021,6 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// k_stream_hits — BvhInterface::intersect on the primary rays of a frame by the STREAMING walk (rt_stream.h):
-// persistent waves, every lane takes its next ray (8x8-pixel tiles in row-major order, a tile's pixels row by row)
-// from the launch's counter when its current one is finished. Experiment / diagnostic entry (rt_debug_stream_hits).
-// Rays the wide engine cannot decide get prim = -2 here (the caller counts them).
-// ---------------------------------------------------------------------------------------------
-struct StreamHitsSrc {
-    const IntersectArgs& a;
-    // The launch's rays in 64 contiguous parts with a counter each (32 words apart: a line of its own — tens of
-    // thousands of atomics on ONE word serialise in its L2 channel at ~50 ns each). A wave takes GRANTS of kGrant
-    // rays from a part (one atomic) and hands them to its lanes as they ask; when its part is empty it looks at all
-    // 64 counters at once (lane i reads counter i: one round trip) and moves to the fullest one.
-    static constexpr uint32_t kGrant = 128u;
-    uint32_t* counters;
-    uint32_t total, tiles_x, part_size;
-    uint32_t part, next, end; // wave-uniform: current part, the granted range [next, end)
-    bool exhausted;
-    RT_DEV bool fetch(bool need, RayL& ray, float& t0, uint32_t& id)
-    {
-        uint64_t m = ballot(need);
-        bool got = false;
-        const uint32_t lane = lane_id();
-        while (m != 0ull && !exhausted) {
-            if (next == end) { // a new grant
-                uint32_t base = 0u;
-                if (lane == 0u)
-                    base = atomicAdd(counters + part * 32u, kGrant);
-                base = read_lane(base, 0u);
-                const uint32_t lo = part * part_size, hi = lo + part_size < total ? lo + part_size : total;
-                if (lo + base < hi) {
-                    next = lo + base, end = next + kGrant < hi ? next + kGrant : hi;
-                } else { // this part is empty: which parts still hold rays?
-                    const uint32_t c = counters[lane * 32u];
-                    const uint32_t plo = lane * part_size, phi = plo + part_size < total ? plo + part_size : total;
-                    const uint32_t left = plo < phi && plo + c < phi ? phi - (plo + c) : 0u;
-                    const uint64_t nonempty = ballot(left != 0u);
-                    if (nonempty == 0ull) {
-                        exhausted = true;
-                        break;
-                    }
-                    // the fullest part (a few waves may pick the same one: the atomic sorts that out)
-                    uint32_t best = left, who = lane;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const uint32_t ob = (uint32_t)__shfl_xor((int)best, o, 64), ow = (uint32_t)__shfl_xor((int)who, o, 64);
-                        if (ob > best || (ob == best && ow < who))
-                            best = ob, who = ow;
-                    }
-                    part = uni(who);
-                    continue;
-                }
-            }
-            const uint32_t avail = end - next;
-            const uint32_t k = prefix_count(m);
-            const bool mine = ((m >> lane) & 1ull) != 0ull && k < avail;
-            if (mine) {
-                const uint32_t idx = next + k;
-                const uint32_t tile = idx >> 6, p = idx & 63u;
-                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-                const int32_t x = (int32_t)(tx * 8u + (p & 7u)), y = (int32_t)(ty * 8u + (p >> 3));
-                if (x < a.cam.width && y < a.cam.height) {
-                    ray = camera_ray(a.cam, x, y);
-                    t0 = kFltMax;
-                    id = (uint32_t)(a.cam.height - 1 - y) * (uint32_t)a.cam.width + (uint32_t)x;
-                    got = true;
-                }
-            }
-            const uint32_t taken = (uint32_t)__builtin_popcountll(m) < avail ? (uint32_t)__builtin_popcountll(m) : avail;
-            next += taken;
-            m &= ~ballot(mine);
-        }
-        return got;
-    }
-    RT_DEV void emit(bool done, uint32_t id, const RayL& ray, unsigned long long key, bool redo)
-    {
-        if (!done)
-            return;
-        float t = kFltMax;
-        int32_t prim = -1;
-        if (redo) {
-            prim = -2;
-        } else if (key != kNoHit) {
-#ifdef RT_STREAM_NOCHECK
-            t = __uint_as_float((uint32_t)(key >> 32));
-            prim = (int32_t)key_index(key);
-#else
-            const int32_t pos = (int32_t)key_index(key);
-            const PrimRecord rec = a.sv.prims[pos];
-            t = tri_plane_t(rec, ray);
-            prim = rec.prim_id;
-#endif
-        }
-        if (a.t_bits)
-            a.t_bits[id] = __float_as_uint(t);
-        if (a.prim)
-            a.prim[id] = prim;
-    }
-};
-
-__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void k_stream_hits(const IntersectArgs a, uint32_t* counter)
-{
-    __shared__ WaveLds lds;
-    const uint32_t lane = lane_id();
-    LaneCounters lc;
-    const SceneView& sv = a.sv;
-    uint32_t flush_at = sv.leaf_flush < kWideFlushMax ? sv.leaf_flush : kWideFlushMax;
-    StreamWalk<0, true> sw { { sv, lds, lc, lane, make_rsrc(sv.wide_nodes, sv.wide_n_nodes * 128u),
-        make_rsrc(sv.wide_leaf, sv.wide_n_groups * 4u * 48u), make_rsrc(sv.wide_index, sv.wide_n_groups * 4u * 4u),
-#ifdef RT_DIAG
-        make_rsrc(sv.diag_wnodes, sv.wide_n_nodes * 128u), make_rsrc(sv.diag_wleaf, sv.wide_n_groups * 4u * 48u),
-#endif
-        0u, flush_at < 1u ? 1u : flush_at } };
-    const uint32_t tiles_x = ((uint32_t)a.cam.width + 7u) / 8u, tiles_y = ((uint32_t)a.cam.height + 7u) / 8u;
-    const uint32_t total = tiles_x * tiles_y * 64u;
-    const uint32_t part_size = ((total + 63u) / 64u + 63u) & ~63u;
-    StreamHitsSrc src { a, counter, total, tiles_x, part_size, blockIdx.x & 63u, 0u, 0u, false };
-    sw.run(src);
-    { // diagnostic sums behind the chunk counters
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(counter + 512u * 32u);
-        const uint32_t nf = wave_sum(lc.node_fetch), bx = wave_sum(lc.box), tr = wave_sum(lc.tri);
-        if (lane == 0) {
-            atomicAdd(d + 0, (unsigned long long)lc.grp);
-            atomicAdd(d + 1, (unsigned long long)lc.sph);
-            atomicAdd(d + 2, (unsigned long long)lc.exact_rays);
-            atomicAdd(d + 3, (unsigned long long)nf);
-            atomicAdd(d + 4, (unsigned long long)bx);
-            atomicAdd(d + 5, (unsigned long long)tr);
-            atomicAdd(d + 6, (unsigned long long)lc.tri_fetch);
-            atomicAdd(d + 7, (unsigned long long)lc.empty_ticks_node);
-            atomicAdd(d + 8, (unsigned long long)lc.empty_ticks_flush);
-            atomicAdd(d + 9, (unsigned long long)lc.empty_ticks_total);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_fold(const FoldArgs a)
 {
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;
@@ -1705,11 +1568,6 @@ void launch_intersect(const IntersectArgs& a, bool count, hipStream_t s)
         hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), 0, s, a);
-}
-
-void launch_stream_hits(const IntersectArgs& a, uint32_t* counter, uint32_t waves, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_stream_hits, dim3(waves), dim3(64), 0, s, a, counter);
 }
 
 void launch_div_check(uint32_t seed, uint32_t mode, uint32_t blocks, uint32_t per_thread, unsigned long long* out,
