@@ -445,7 +445,7 @@ class Bench:
                "alone": {"launch_us": round(dur * 1e6, 2), "launches": len(alone),
                          "frames_per_launch": main_size, "each_us": [round(x * 1e3, 1) for x in res["alone_ms"]],
                          "note": "ONE launch of the main shape in flight, host-synchronised between launches: the "
-                                 "duration a launch has to itself (the first one is not averaged)"
+                                 "duration a launch has to itself (mean over launches spread over the orbit, after one discarded launch)"
                          if alone_s else "no alone pass: the timed launches' own average (they overlap)"},
                "algorithmic": {"bytes_per_launch": int(per_launch_bytes),
                                "rate_gbs": round(per_launch_bytes / dur / 1e9, 2),

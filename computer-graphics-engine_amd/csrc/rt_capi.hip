@@ -1263,7 +1263,7 @@ int rt_render(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* fe
         if (features->enableSoftShadow)
             for (const rt::LightRec& l : bvh->scene->host.lights)
                 heavy = heavy || l.kind != RT_LIGHT_POINT;
-        n_bands = heavy ? 1 : 4;
+        n_bands = heavy ? 1 : ((int64_t)width * height >= (int64_t)6 << 20 ? 8 : 4); // 4K frames: the copy dominates, finer bands
     }
     if (!counters && !features->enableBloomEffect && n_bands > 1 && row_end - row_begin >= 64 * n_bands) {
         for (auto& s_ : bvh->host_stream)

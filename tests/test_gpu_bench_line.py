@@ -84,7 +84,7 @@ def test_the_drivers_command_every_ceiling_is_a_fraction_and_every_config_has_a_
     ref = r.get("profile_alone_launch_us")
     if ref:
         mine = r["alone"]["launch_us"] * 8.0 / r["alone"]["frames_per_launch"]
-        assert abs(mine - ref) <= 0.05 * ref, (mine, ref)
+        assert abs(mine - ref) <= 0.15 * ref, (mine, ref)   # box-to-box spread of this issue-bound kernel: +-10 % (profiles/r03_notes.md)
     w = d["workloads"]
     assert set(w) == {"C2", "C4", "C5"}
     for name, x in w.items():

@@ -106,7 +106,8 @@ if kt:
     rows = [r for r in csv.DictReader(open(kt)) if trace_kernel(r["Kernel_Name"])]
     t0 = min(int(r["Start_Timestamp"]) for r in rows) if rows else 0
     for r in rows:
-        shape_rows.append({"kernel": r["Kernel_Name"][:60], "grid_threads": int(r["Grid_Size"]),
+        gsz = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+        shape_rows.append({"kernel": r["Kernel_Name"][:60], "grid_threads": gsz,
                            "frames": None, "stream_or_queue": r.get("Queue_Id", ""),
                            "start_us": round((int(r["Start_Timestamp"]) - t0) / 1e3, 1),
                            "duration_us": round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1)})
