@@ -533,7 +533,8 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
         for (const rt::LightRec& l : bvh->scene->host.lights)
             if (l.kind != RT_LIGHT_POINT)
                 area_lights = true;
-    a.lean = !area_lights && !f.enableNormalInterp && !f.enableTextureMapping && bvh->scene->host.spheres.empty() ? 1u : 0u;
+    const bool tris_only = bvh->scene->host.spheres.empty(), attrs = f.enableNormalInterp || f.enableTextureMapping;
+    a.variant = tris_only && !area_lights ? (attrs ? 2u : 1u) : 0u;
     a.tile_cull = g_tile_cull.load() && !counters_dev ? 1u : 0u; // the counting pass traces every primary ray
     a.tile_cull_count = g_tile_cull.load() && counters_dev ? 1u : 0u;
     a.skip_unlit = g_skip_unlit.load() ? 1u : 0u;

@@ -71,8 +71,8 @@ struct LevelArgs {
     uint32_t tile_cull;       // 1: primary tiles that cannot reach the scene bounds skip the traversal
     uint32_t skip_unlit;      // 1: no shadow ray where the light's colour at the hit is exactly zero (shade_hit)
     uint32_t tile_cull_count; // counting pass: 1 = count (and still trace) the primary rays tile_cull would skip
-    uint32_t lean;            // 1: point lights only (or soft shadows off), triangles only, no normal interpolation /
-                              //    textures: the lean kernel variant renders it
+    uint32_t variant;         // which k_trace_level variant renders the launch (rt_kernels.hip: 0 everything, 1 lean,
+                              //    2 lean + hit attributes)
     RaySoA out;
     uint32_t* out_count;
     float* direct;   // this level's direct-light colours, n_items * 3

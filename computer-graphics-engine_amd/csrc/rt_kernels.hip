@@ -315,7 +315,8 @@ struct MergeNext {
 // LEAN: the kernel variant for the common plain case — point lights only (or soft shadows off),
 // triangles only, no normal interpolation, no textures; none of that code is compiled in (the
 // area-light code alone costs the point-light path 2 % through register allocation).
-template <bool COUNT, bool GENERAL, bool LEAN>
+// NOSPH: the scene holds triangles only (no sphere test in the shadow traversals)
+template <bool COUNT, bool GENERAL, bool LEAN, bool NOSPH = LEAN>
 RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int32_t pos, int32_t level, uint32_t pixel,
     const HitL& h, LaneCounters& lc, RayCounts& rc, WaveLds& wl, MergeNext* mg)
 {
@@ -389,7 +390,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                         if (need && known >= 0 && wide_known_blocker<COUNT>(sv, sray, (uint32_t)known, lc))
                             need = false, by_known = true;
                     }
-                    traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
+                    traverse<Q_ANY, COUNT, NOSPH>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
                     if (spos >= 0)
                         known = spos;
                     const int blocked = (spos >= 0 || by_known) ? 1 : 0;
@@ -442,7 +443,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                         && __builtin_popcountll(m_c) <= 32 && __builtin_popcountll(m_a) <= 32) {
                         float tq = kFltMax;
                         int32_t pq, pa;
-                        traverse_pair<COUNT, LEAN>(sv, prune, mg->spawn, mg->refl, prefix_count(m_c), tq, pq, need, sray,
+                        traverse_pair<COUNT, NOSPH>(sv, prune, mg->spawn, mg->refl, prefix_count(m_c), tq, pq, need, sray,
                             32u + prefix_count(m_a), 1.0f, pa, lc, wl);
                         mg->pos = pq, mg->t = tq, mg->done = true;
                         if (pa >= 0) {
@@ -450,7 +451,7 @@ RT_DEV V3 shade_hit(const LevelArgs& a, bool hit, const RayL& ray, float t, int3
                             last_blocker = pa;
                         }
                     } else if (!GENERAL || !(flags & F_TRANSPARENCY)) {
-                        traverse<Q_ANY, COUNT, LEAN>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
+                        traverse<Q_ANY, COUNT, NOSPH>(sv, use_bvh, prune, need, sray, st, spos, lc, wl);
                         if (spos >= 0) {
                             visibility = 0.0f;
                             last_blocker = spos;
@@ -818,9 +819,19 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_general(con
 
 // MULTI: several frames in one launch (CameraArgs::n_frames > 1): the tile's frame comes from its row entries,
 // the camera pose from LevelArgs::poses — a variant of its own, the one-frame kernels carry none of it.
-template <bool COUNT, bool LEAN, bool MULTI = false>
+// VAR: which code the variant carries. Register allocation of the traversal loops is sensitive to everything else in
+// the kernel (the area-light code alone costs the point-light case 3.5 %, the general variant spills 280 bytes per
+// lane — at 4K that scratch write-back was 40 % of a C5 frame's HBM traffic), so the common cases get kernels of their own:
+//   0  everything: spheres, area lights with soft shadows, normal interpolation, textures (and the counting kernel)
+//   1  lean: point lights only (or soft shadows off), triangles only, flat normals, no textures (C2, C3)
+//   2  lean + hit attributes: as 1 with normal interpolation and / or textures (C5)
+// (A fourth variant — area lights on triangles with flat normals, C4 — measured the same as variant 0: 2.456 vs 2.444 ms.)
+template <bool COUNT, int VAR, bool MULTI = false>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const LevelArgs a)
 {
+    constexpr bool LEAN = VAR == 1 || VAR == 2; // no area-light code
+    constexpr bool NOSPH = VAR != 0;            // triangles only
+    constexpr bool FLAT = VAR == 1;             // flat normals, no textures
     const uint32_t lane = lane_id();
     const uint32_t wave = uni(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     const SceneView& sv = a.sv;
@@ -945,7 +956,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         t = mg.t;
         mg.done = false;
     } else {
-        traverse<Q_CLOSEST, COUNT, LEAN>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
+        traverse<Q_CLOSEST, COUNT, NOSPH>(sv, use_bvh, prune, active, ray, t, pos, lc, wl);
     }
     const bool hit = active && pos >= 0;
     if (active) {
@@ -961,7 +972,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
     h.normal = mk(0, 0, 1), h.kd = mk(0, 0, 0), h.ks = mk(0, 0, 0);
     h.shininess = 1.0f, h.transparency = 1.0f, h.texture = -1;
     if (hit)
-        resolve_hit<LEAN>(sv, flags, ray, t, pos, h);
+        resolve_hit<FLAT>(sv, flags, ray, t, pos, h);
     if (COUNT && hit)
         rc.hits = 1;
 
@@ -974,7 +985,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) void k_trace_level(const
         spawn = compute_reflection_ray(ray, t, h, refl);
     mg.spawn = spawn, mg.refl = refl;
 
-    const V3 Lo = shade_hit<COUNT, false, LEAN>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, &mg);
+    const V3 Lo = shade_hit<COUNT, false, LEAN, NOSPH>(a, hit, ray, t, pos, level, pixel, h, lc, rc, wl, &mg);
     if (hit) {
         float* d = a.direct + (size_t)(level - first_level) * a.level_stride + 3 * (size_t)item;
         d[0] = Lo.x, d[1] = Lo.y, d[2] = Lo.z;
@@ -1486,17 +1497,23 @@ void launch_trace_level(const LevelArgs& a, bool count, hipStream_t s)
     if (waves == 0)
         return;
     const uint32_t grid = grid_for_waves(waves);
+    const bool multi = a.source == SRC_CAMERA && a.cam.n_frames > 1;
+#define RT_LAUNCH_TRACE(VAR)                                                                                              \
+    do {                                                                                                                  \
+        if (multi)                                                                                                        \
+            hipLaunchKernelGGL((k_trace_level<false, VAR, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);            \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_trace_level<false, VAR, false>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);           \
+    } while (0)
     if (count)
-        hipLaunchKernelGGL((k_trace_level<true, false>), dim3(grid), dim3(kBlock), 0, s, a);
-    else if (a.source == SRC_CAMERA && a.cam.n_frames > 1) {
-        if (a.lean)
-            hipLaunchKernelGGL((k_trace_level<false, true, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
-        else
-            hipLaunchKernelGGL((k_trace_level<false, false, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
-    } else if (a.lean)
-        hipLaunchKernelGGL((k_trace_level<false, true>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
+        hipLaunchKernelGGL((k_trace_level<true, 0>), dim3(grid), dim3(kBlock), 0, s, a);
+    else if (a.variant == 1)
+        RT_LAUNCH_TRACE(1);
+    else if (a.variant == 2)
+        RT_LAUNCH_TRACE(2);
     else
-        hipLaunchKernelGGL((k_trace_level<false, false>), dim3(grid), dim3(kBlock), g_lds_pad, s, a);
+        RT_LAUNCH_TRACE(0);
+#undef RT_LAUNCH_TRACE
 }
 
 uint32_t trace_general_waves(const LevelArgs& a)
