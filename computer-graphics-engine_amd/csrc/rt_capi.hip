@@ -1253,6 +1253,19 @@ int rt_render(const rt_bvh* cbvh, const rt_camera* camera, const rt_features* fe
         return rc;
     std::lock_guard<std::mutex> g(g_host_call_mu);
     const size_t frame_floats = (size_t)width * height * 3;
+    // the handle's device, whatever the calling thread's current device is (a fresh std::thread starts on device 0)
+    int caller_device = 0;
+    HIP_TRY(hipGetDevice(&caller_device));
+    struct RestoreDevice {
+        int d, mine;
+        ~RestoreDevice()
+        {
+            if (d != mine)
+                (void)hipSetDevice(d);
+        }
+    } restore_device { caller_device, bvh->scene->device };
+    if (caller_device != bvh->scene->device)
+        HIP_TRY(hipSetDevice(bvh->scene->device));
     // A frame for the caller's HOST buffer (what renderRayTracing -> Screen asks for): the copy back costs as much
     // as the render, so the frame goes out as bands of rows on two alternating streams and every band is copied
     // back (third stream) while the later bands render. Same launches per band as rt_render_device with a row range:

@@ -80,3 +80,42 @@ def test_concurrent_threads_with_a_stream_each(rt, abi, scenes):
     assert not errors, errors
     for i in range(n):
         assert np.array_equal(frames[i].cpu().numpy().view(np.uint32), serial[i].view(np.uint32)), f"camera {i}"
+
+
+def test_concurrent_host_frames_in_bands_share_one_bvh(rt, abi, scenes):
+    """Frames large enough for the banded host path (rows on alternating streams, copies back on a third), from more
+    threads than the handle has host-call slots: every thread gets the bits of its own camera, call after call."""
+    data = scenes.load_fixture_scene("monkey")
+    f = abi.Features.make(enableShading=1, enableHardShadow=1, enableRecursive=1, enableAccelStructure=1)
+    p = abi.RenderParams.make(depth=2)
+    bvh = rt.bvh(rt.scene(data), f)
+    W, H, n = 352, 304, 7
+    cams = _cameras(scenes, W, H, n)
+    rt.set_option("host_bands", 1)
+    try:
+        serial = [rt.render(bvh, rt.camera(*c), f, p, W, H) for c in cams]
+    finally:
+        rt.set_option("host_bands", 0)
+    assert not np.array_equal(serial[0], serial[1])
+    errors, bad = [], []
+
+    def work(i):
+        try:
+            for k in range(4):
+                got = rt.render(bvh, rt.camera(*cams[i]), f, p, W, H)
+                if not np.array_equal(got.view(np.uint32), serial[i].view(np.uint32)):
+                    bad.append((i, k))
+                if k == 1:      # a counting call in between (one launch, the slot's counters)
+                    _, cnt = rt.render(bvh, rt.camera(*cams[i]), f, p, W, H, count=True)
+                    if cnt.rays_primary != W * H:
+                        bad.append((i, "count"))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert not bad, bad
