@@ -162,19 +162,24 @@ class Settings:
             opts = {"tile_wlog": 3, "tile_hlog": 3, "leaf_flush": 32}
         elif mode == "flight":
             opts = {"tile_wlog": 2, "tile_hlog": 3, "leaf_flush": 16}
-        else:  # "latency": the library defaults
-            opts = {"tile_wlog": 2, "tile_hlog": 2, "leaf_flush": 16}
+        else:  # "latency": the library defaults — the tile shape picked per frame type (tile_auto)
+            opts = {"leaf_flush": 16, "tile_auto": 1}
         # shares of frames: the launches in flight must really run side by side (the one-launch tile order does not
         # queue up behind the running trace kernel the way the count / scan / scatter kernels do)
         opts["order_one_launch"] = 2 if (self.world > 1 or a.exchange_always) and mode != "latency" else 1
         if a.tile_log and mode != "latency":
             opts["tile_wlog"], opts["tile_hlog"] = a.tile_log
+        opts.pop("tile_auto", None) if "tile_wlog" in opts else None
         for kv in a.set:
             k_, v_ = kv.split("=")
             opts[k_] = int(v_)
+        self.rt.set_option("tile_hlog", 0)   # any (wlog, hlog) pair is reachable from here (their sum is bounded)
         for k_, v_ in opts.items():
-            self.rt.set_option(k_, v_)
-        self.tiles = [opts["tile_wlog"], opts["tile_hlog"]]
+            if k_ != "tile_auto":
+                self.rt.set_option(k_, v_)
+        if "tile_auto" in opts:               # last: setting a shape switches it off
+            self.rt.set_option("tile_auto", opts["tile_auto"])
+        self.tiles = [opts.get("tile_wlog"), opts.get("tile_hlog")]
         return ", ".join(f"{k_}={v_}" for k_, v_ in sorted(opts.items()))
 
 

@@ -41,6 +41,13 @@ std::atomic<int> g_wide { 1 };
 // rt_set_option("prefetch", 1): the wide engine touches the next node's line at the end of a step
 std::atomic<int> g_xcd_order { 1 }, g_prefetch { 0 }, g_xcd_block { 4 }, g_frame_major { 1 }, g_skip_unlit { 1 }, g_order_one_launch { 1 };
 // rt_set_option("tile_wlog"/"tile_hlog"/"min_waves"): primary tile shape, sparse-level packing (tuning)
+// "tile_auto" 1 (default; switched off by setting tile_wlog / tile_hlog): ONE-frame camera launches pick their tile
+// shape by what the frame is — a row of 32 x 1 pixels (64 x 1 from 4 Mpixel up) for point lights on triangles: a
+// row mixes cheap and expensive path trees in one wave where a square tile inside the object holds only expensive
+// ones, and 32 - 64 rays per wave cost fewer instructions per ray than 16 (lone C3 frame 0.56 -> 0.49 ms over the
+// orbit, C5 2.42 -> 1.47, C2 0.153 -> 0.12 against 4 x 4); 4 x 4 for area lights, whose 64 samples per hit make a
+// wave of 32 or 64 hits last too long (C4 3.5 ms against 4.3 / 5.8) — profiles/r03_notes.md §7
+std::atomic<int> g_tile_auto { 1 };
 std::atomic<int> g_tile_wlog { 2 }, g_tile_hlog { 2 }, g_min_waves { 4096 }, g_super_log { 0 }, g_fused { 1 }, g_tile_order { 1 }, g_fused_from { 0 }, g_merge_next { 1 }, g_tile_cull { 1 }, g_launch_rect { 1 };
 unsigned long long* g_stamps = nullptr; // diagnostic builds: rt_debug_stamps
 
@@ -540,6 +547,15 @@ int enqueue_trace(rt_bvh* bvh, Scratch& sc, const rt_features& f, const rt_rende
     a.skip_unlit = g_skip_unlit.load() ? 1u : 0u;
     a.level_stride = (size_t)n_items * 3;
     a.cam = cam;
+    if (g_tile_auto.load() && source == rt::SRC_CAMERA && cam.n_frames <= 1 && cam.super_log == 0) {
+        // one frame in the launch: the tile shape that suits the frame (g_tile_auto)
+        // point lights on triangles: a row of 32 pixels per wave (64 from 4 Mpixel up); area lights, spheres: 4 x 4
+        const bool rows = a.variant != 0u, big = (int64_t)cam.vwidth * cam.height >= (int64_t)4 << 20;
+        a.cam.tile_wlog = rows ? (big ? 6u : 5u) : 2u, a.cam.tile_hlog = rows ? 0u : 2u;
+        a.sv.leaf_flush = rows ? (big ? 32u : 24u) : 16u;
+        if (a.sv.leaf_flush > rt::kWideFlushMax && a.sv.wide_ok)
+            a.sv.leaf_flush = rt::kWideFlushMax;
+    }
     bool rect = false, counts_zeroed = false;
     if (source == rt::SRC_CAMERA && !counters_dev && (flags & rt::F_ACCEL) && !(flags & rt::F_NO_PRUNE)) {
         rect = host_launch_rect(bvh, a.cam);
@@ -720,9 +736,12 @@ int rt_set_option(const char* name, int value)
         return RT_OK;
     }
     if (name && (strcmp(name, "tile_wlog") == 0 || strcmp(name, "tile_hlog") == 0)) {
-        if (value < 0 || value > 3)
-            return fail(RT_ERR_INVALID, "rt_set_option: tile_wlog / tile_hlog must be in [0, 3]");
-        (name[5] == 'w' ? g_tile_wlog : g_tile_hlog).store(value);
+        // a tile is one wave's primary rays: at most 64 pixels; its height divides the 8-row strips
+        const bool w_ = name[5] == 'w';
+        if (value < 0 || value > (w_ ? 6 : 3) || value + (w_ ? g_tile_hlog : g_tile_wlog).load() > 6)
+            return fail(RT_ERR_INVALID, "rt_set_option: tile_wlog in [0, 6], tile_hlog in [0, 3], tile_wlog + tile_hlog <= 6");
+        (w_ ? g_tile_wlog : g_tile_hlog).store(value);
+        g_tile_auto.store(0); // an explicit shape is meant
         return RT_OK;
     }
     if (name && strcmp(name, "fused") == 0) { // 1: all recursion levels in one launch (default); 0: one launch per level
@@ -803,6 +822,10 @@ int rt_set_option(const char* name, int value)
         if (value < 0 || value > 8)
             return fail(RT_ERR_INVALID, "rt_set_option: host_bands must be in [0, 8] (0 = automatic)");
         g_host_bands.store(value);
+        return RT_OK;
+    }
+    if (name && strcmp(name, "tile_auto") == 0) {
+        g_tile_auto.store(value != 0);
         return RT_OK;
     }
     if (name && strcmp(name, "leaf_flush") == 0) {

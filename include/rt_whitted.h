@@ -213,7 +213,9 @@ int rt_device_info(int* device_count, char* name_buf, size_t name_buf_len);
  * GroupRecord) — results are identical bit for bit.
  * Scheduling / tuning options, none of which changes any result: "fused" (1: all
  * recursion levels in one launch), "fused_from", "tile_wlog" / "tile_hlog" (primary
- * tile = 2^w x 2^h pixels per wave), "tile_order" (1: centre-first dispatch),
+ * tile = 2^w x 2^h pixels per wave, w + h <= 6; setting either switches "tile_auto" off), "tile_auto" (1, the default:
+ * one-frame launches pick the tile by what the frame is — a row of 32 or 64 pixels for point lights on triangles, 4 x 4
+ * for area lights), "tile_order" (1: centre-first dispatch),
  * "leaf_flush", "min_waves", "super_log", "tile_cull", "launch_rect", "merge_next", "wide" (0: the
  * exact-topology engine alone), "xcd_order" / "xcd_block" (screen blocks of 2^v pixels a side per XCD),
  * "frame_major", "order_one_launch" (the tile order built in one launch: 1 for lone frames, 2 always, 0 never), "skip_unlit"

@@ -2,7 +2,7 @@
 gives the bits of the default one — tile shapes (the bench's throughput setting is 8x8), per-level launches
 instead of the fused recursion, no merged traversals, row-major tile order, no tile culling / launch rectangle,
 XCD super-tiles, leaf-queue thresholds, the exact-topology engine alone (wide=0), the XCD-aware tile order, the
-node prefetch — for full frames, packed strips and several frames per launch."""
+node prefetch, explicit tile shapes against the automatic one (tile_auto) — for full frames, packed strips and several frames per launch."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = dict(tile_wlog=2, tile_hlog=2, fused=1, fused_from=0, merge_next=1, tile_order=1, tile_cull=1, launch_rect=1,
-                super_log=0, leaf_flush=16, min_waves=4096, wide=1, xcd_order=1, xcd_block=4, prefetch=0, frame_major=1, skip_unlit=1, order_one_launch=1)
+                super_log=0, leaf_flush=16, min_waves=4096, wide=1, xcd_order=1, xcd_block=4, prefetch=0, frame_major=1, skip_unlit=1, order_one_launch=1, tile_auto=1)
 SETTINGS = [
     dict(tile_wlog=3, tile_hlog=3), dict(tile_wlog=2, tile_hlog=3), dict(tile_wlog=3, tile_hlog=2),
     dict(tile_wlog=1, tile_hlog=3), dict(tile_wlog=0, tile_hlog=0), dict(tile_wlog=3, tile_hlog=0), dict(tile_wlog=0, tile_hlog=3),
@@ -18,6 +18,7 @@ SETTINGS = [
     dict(tile_order=0), dict(tile_cull=0), dict(launch_rect=0), dict(tile_cull=0, launch_rect=0, tile_order=0),
     dict(super_log=1), dict(leaf_flush=1), dict(leaf_flush=32, tile_wlog=3, tile_hlog=3), dict(leaf_flush=36), dict(leaf_flush=4, tile_wlog=3, tile_hlog=3), dict(min_waves=1),
     dict(wide=0), dict(xcd_order=0), dict(xcd_order=0, tile_wlog=3, tile_hlog=3), dict(prefetch=1), dict(xcd_block=0, prefetch=1, launch_rect=0), dict(xcd_block=6), dict(frame_major=0), dict(skip_unlit=0), dict(skip_unlit=0, tile_wlog=3, tile_hlog=3),
+    dict(tile_auto=0), dict(tile_hlog=0, tile_wlog=6), dict(tile_hlog=1, tile_wlog=5, leaf_flush=32), dict(tile_wlog=4, tile_hlog=2),
     dict(order_one_launch=0), dict(order_one_launch=2), dict(order_one_launch=2, xcd_order=0, tile_wlog=3, tile_hlog=3),
 ]
 
