@@ -18,7 +18,8 @@ on every launch stream (StripRenderer.prepare), whatever --warmup says.
 After the C3 region the same protocol times BASELINE.json's other GPU configs — `workloads`: C2, C4, C5 at N = 1; C4
 (the config BASELINE assigns to 8 GPUs at 1080p) at N > 1 — with --workload-steps frames each, so that every config has
 a figure observed by whoever runs this file. `frame_ms_serial` is the other extreme of the protocol: one frame per
-launch, one launch at a time, host-synchronised, the library's default tiles; `frame_ms_host_call` is the drop-in call
+launch, one launch at a time, host-synchronised, the library's own choice of tile (tile_auto: rows of 32 / 64 pixels
+for point lights on triangles, 4x4 for area lights); `frame_ms_host_call` is the drop-in call
 itself: rt_render into a host buffer (what renderRayTracing → Screen costs), PCIe included — never `value`.
 
 N GPUs: one process per GPU (started by torch.distributed.run — or by this file itself: `python bench.py --gpus N`
@@ -169,10 +170,11 @@ class Settings:
         opts["order_one_launch"] = 2 if (self.world > 1 or a.exchange_always) and mode != "latency" else 1
         if a.tile_log and mode != "latency":
             opts["tile_wlog"], opts["tile_hlog"] = a.tile_log
-        opts.pop("tile_auto", None) if "tile_wlog" in opts else None
         for kv in a.set:
             k_, v_ = kv.split("=")
             opts[k_] = int(v_)
+        if ("tile_wlog" in opts or "tile_hlog" in opts) and not any(kv.startswith("tile_auto=") for kv in a.set):
+            opts.pop("tile_auto", None)   # an explicit shape is meant
         self.rt.set_option("tile_hlog", 0)   # any (wlog, hlog) pair is reachable from here (their sum is bounded)
         for k_, v_ in opts.items():
             if k_ != "tile_auto":
