@@ -20,10 +20,10 @@ st = torch.cuda.current_stream().cuda_stream
 R = sharding.StripRenderer(rt, bvh, cams[0], f, p, W, H)
 res = {}
 per_pose = {}
-settings = [(2, 2, 16), (6, 0, 32), (5, 0, 24), (4, 1, 24), (3, 1, 24), (3, 2, 24)]
+settings = [(2, 2, 16), (3, 1, 16), (4, 0, 16), (4, 1, 24), (5, 0, 24), (6, 0, 32), (3, 2, 24), (3, 3, 32)]  # (tile_wlog, tile_hlog, leaf_flush[, xcd_block])
 for rnd in range(3):
     for s in settings:
-        rt.set_option("tile_hlog", 0); rt.set_option("tile_wlog", s[0]); rt.set_option("tile_hlog", s[1]); rt.set_option("leaf_flush", s[2])
+        rt.set_option("tile_hlog", 0); rt.set_option("tile_wlog", s[0]); rt.set_option("tile_hlog", s[1]); rt.set_option("leaf_flush", s[2]); rt.set_option("xcd_block", s[3] if len(s) > 3 else 4)
         R.step(st, cams=[cams[0]]); torch.cuda.synchronize()
         ts = []
         for c in cams:
@@ -34,4 +34,4 @@ for rnd in range(3):
         per_pose.setdefault(s, []).append(ts)
 for s in settings:
     pp = np.median(np.array(per_pose[s]), axis=0) * 1e3
-    print(f"{wl} tile 2^{s[0]} x 2^{s[1]} leaf_flush {s[2]:2d}: lone frame mean over the orbit {np.median(res[s]):.4f} ms (min {min(res[s]):.4f})  by pose: " + " ".join(f"{v:.2f}" for v in pp))
+    print(f"{wl} tile 2^{s[0]} x 2^{s[1]} leaf_flush {s[2]:2d} xcd_block {s[3] if len(s) > 3 else 4}: lone frame mean over the orbit {np.median(res[s]):.4f} ms (min {min(res[s]):.4f})  by pose: " + " ".join(f"{v:.2f}" for v in pp))
