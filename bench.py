@@ -161,6 +161,14 @@ class Settings:
             # prefers the library default. 64-ray waves fill a longer leaf queue before a flush pays.
             # Results are identical for every setting (tests/test_gpu_options.py).
             opts = {"tile_wlog": 3, "tile_hlog": 3, "leaf_flush": 32}
+            # several ranks: a launch holds only 1 / N of its frames' rows, so the launch's tail — the longest path
+            # trees of its tiles — weighs more; rows of pixels mix cheap and expensive path trees in one wave and end
+            # sooner (one rank's share of the 20-frame region, tools/share_region.py: 1.10 -> 0.89 ms at 8 ranks,
+            # 1.64 -> 1.46 at 4, 2.51 -> 2.41 at 2 with 16 x 4; at one rank 8 x 8 stays best: 4.21 against 4.31 - 4.36)
+            if self.world >= 4:
+                opts.update(tile_wlog=6, tile_hlog=0)
+            elif self.world == 2:
+                opts.update(tile_wlog=4, tile_hlog=2)
         elif mode == "flight":
             opts = {"tile_wlog": 2, "tile_hlog": 3, "leaf_flush": 16}
         else:  # "latency": the library defaults — the tile shape picked per frame type (tile_auto)

@@ -29,7 +29,8 @@ W, H = cfg.width, cfg.height
 fovy, aspect, look_at, dist_, rot0 = scenes.default_camera_args(W, H)
 N = 20
 cams = [rt.camera(fovy, aspect, look_at, dist_, (rot0[0], rot0[1] + 2 * math.pi * k / N, rot0[2])) for k in range(N)]
-rt.set_option("tile_wlog", 3), rt.set_option("tile_hlog", 3), rt.set_option("leaf_flush", 32)
+TW, TH, FLUSH = int(os.environ.get("TILE_W", "3")), int(os.environ.get("TILE_H", "3")), int(os.environ.get("FLUSH", "32"))
+rt.set_option("tile_hlog", 0), rt.set_option("tile_wlog", TW), rt.set_option("tile_hlog", TH), rt.set_option("leaf_flush", FLUSH)
 rt.set_option("order_one_launch", int(os.environ.get("ONE", "2")))
 streams = sharding.new_streams(FLIGHT)
 for s in streams:
@@ -56,5 +57,5 @@ for plan in plans:
         region()
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    print(f"world {WORLD} rank {RANK} order_one_launch {os.environ.get('ONE', '2')} plan {plan}: region {np.median(ts) * 1e3:.3f} ms "
+    print(f"tile 2^{TW} x 2^{TH} flush {FLUSH} world {WORLD} rank {RANK} order_one_launch {os.environ.get('ONE', '2')} plan {plan}: region {np.median(ts) * 1e3:.3f} ms "
           f"= {np.median(ts) * 1e3 / N:.4f} ms per frame (min {min(ts) * 1e3 / N:.4f})", flush=True)
