@@ -153,7 +153,7 @@ class Settings:
     def __init__(self, rt, args, world):
         self.rt, self.args, self.world = rt, args, world
 
-    def apply(self, mode: str) -> str:
+    def apply(self, mode: str, features: dict = None) -> str:
         a = self.args
         if mode == "throughput":
             # 8x8-pixel primary tiles (64 rays per wave) do the least instruction work per ray but end in the longest
@@ -162,13 +162,21 @@ class Settings:
             # Results are identical for every setting (tests/test_gpu_options.py).
             opts = {"tile_wlog": 3, "tile_hlog": 3, "leaf_flush": 32}
             # several ranks: a launch holds only 1 / N of its frames' rows, so the launch's tail — the longest path
-            # trees of its tiles — weighs more; rows of pixels mix cheap and expensive path trees in one wave and end
-            # sooner (one rank's share of the 20-frame region, tools/share_region.py: 1.10 -> 0.89 ms at 8 ranks,
-            # 1.64 -> 1.46 at 4, 2.51 -> 2.41 at 2 with 16 x 4; at one rank 8 x 8 stays best: 4.21 against 4.31 - 4.36)
-            if self.world >= 4:
-                opts.update(tile_wlog=6, tile_hlog=0)
-            elif self.world == 2:
-                opts.update(tile_wlog=4, tile_hlog=2)
+            # trees of its tiles — weighs more. Point lights: rows of pixels mix cheap and expensive path trees in one
+            # wave and end sooner (one rank's share of the 20-frame region, tools/share_region.py: 1.10 -> 0.89 ms at 8
+            # ranks, 1.64 -> 1.46 at 4, 2.51 -> 2.41 at 2 with 16 x 4; at one rank 8 x 8 stays best: 4.21 against 4.31 -
+            # 4.36). Area lights (64 samples per hit): fewer hits per wave (C4: 11.5 -> 8.2 ms at 8 ranks with 4 x 4,
+            # 16.8 -> 14.6 at 4 with 8 x 4; 8 x 8 at one and two ranks). profiles/r03_notes.md §7.
+            area = bool(features and features.get("enableSoftShadow"))
+            if not area:
+                if self.world >= 3:
+                    opts.update(tile_wlog=6, tile_hlog=0)
+                elif self.world == 2:
+                    opts.update(tile_wlog=4, tile_hlog=2)
+            elif self.world >= 6:
+                opts.update(tile_wlog=2, tile_hlog=2, leaf_flush=24)
+            elif self.world >= 3:
+                opts.update(tile_wlog=3, tile_hlog=2, leaf_flush=24)
         elif mode == "flight":
             opts = {"tile_wlog": 2, "tile_hlog": 3, "leaf_flush": 16}
         else:  # "latency": the library defaults — the tile shape picked per frame type (tile_auto)
@@ -268,7 +276,7 @@ class Bench:
 
         fpl_arg = max(1, args.frames_per_launch)
         mode = "throughput" if fpl_arg > 1 else ("flight" if args.frames_in_flight > 1 else "latency")
-        setting = self.settings.apply(mode)
+        setting = self.settings.apply(mode, cfg.features)
         tiles = list(self.settings.tiles)
         renderer = sharding.StripRenderer(rt, bvh, cam, f, p, W, H, self.rank, world, strip_rows=STRIP_ROWS,
                                           frames_in_flight=args.frames_in_flight, exchange_always=args.exchange_always,
@@ -433,7 +441,7 @@ class Bench:
                                 "setting": "rt_render(bvh, camera, ..., float* host_rgb): render + copy into the caller's "
                                            f"pageable buffer ({W * H * 12 / 1e6:.1f} MB), default pose; {lat}"}
             del lone
-            self.settings.apply(mode)
+            self.settings.apply(mode, cfg.features)
         del renderer
         bvh.close()
         scene.close()
